@@ -1,0 +1,262 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+Imports the reference's own modules from /root/reference/Reflected-Diffusion
+(SURVEY.md 8c / Appendix A), loads the seeded synthetic weights of
+oracle/weights.py into the reference NCSNpp with strict=True, and records
+inputs + expected outputs.  Only data is written: no reference source text is
+copied.  /root/reference does not exist on the GPU box; tests read the .npz.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+import hashlib
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/Reflected-Diffusion'
+OUT = os.path.join(HERE, '..', 'tests', 'golden')
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+import cube, sde_lib, sampling, losses            # noqa: E402  (reference modules)
+from models import utils as mutils               # noqa: E402
+from models.ema import ExponentialMovingAverage  # noqa: E402
+import weights as W                              # noqa: E402  (oracle/weights.py)
+
+torch.set_num_threads(8)
+
+
+def make_cfg(image_size=9, image_width=9, dropout=0.2, cond_drop_prob=0.5, corrector='none', num_scales=1000):
+    return NS(
+        model=NS(name='ncsnpp', channels=1, image_size=image_size, image_width=image_width, num_classes=1,
+                 cond_drop_prob=cond_drop_prob, conditional=True, init_scale=0., ema_rate=0.999, nf=64,
+                 ch_mult=[1, 2, 2], num_res_blocks=2, attn_resolutions=[9], resamp_with_conv=True,
+                 embedding_type='fourier', fourier_scale=16, resblock_type='ddpm', skip_rescale=True,
+                 nonlinearity='swish', fir=False, fir_kernel=[1, 3, 3, 1], dropout=dropout, scale_by_sigma=False),
+        sampling=NS(method='pc', n_steps_each=1, noise_removal=True, probability_flow=False, snr=0.01,
+                    predictor='euler_maruyama', corrector=corrector, denoiser='none'),
+        sde=NS(sigma_min=0.01, sigma_max=5, num_scales=num_scales),
+        optim=NS(weight_decay=0, optimizer='Adam', lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, warmup=10000,
+                 grad_clip=0.5),
+        training=NS(reduce_mean=False, likelihood_weighting=False))
+
+
+def ref_model(cfg, seed=0):
+    model = mutils.create_model(cfg)
+    params = W.make_params(seed)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    assert list(sd.keys()) == list(model.state_dict().keys()), 'state-dict order/name mismatch'
+    model.load_state_dict(sd, strict=True)
+    return model.eval(), params
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, keys={len(arrs)}')
+
+
+def gen_cube_sde():
+    known_in = np.array([-2.3, -1.2, -0.3, 1.2, 2.3, 3.7, 1.0, -1.0, 2.0, 0.0, -2.0, 4.0, 0.5, 1e-9, -1e-9, 1.9999999],
+                        np.float32)
+    g = torch.Generator().manual_seed(11)
+    rnd = (torch.rand(4, 1, 9, 9, generator=g) * 14 - 7)
+    out = dict(reflect_known_in=known_in, reflect_known_out=cube.reflect(torch.from_numpy(known_in.copy())).numpy(),
+               reflect_rand_in=rnd.numpy(), reflect_rand_out=cube.reflect(rnd.clone()).numpy())
+    # score_hk across the t = sigma^2/2 = 1e-2 switch (sigma = 0.14142)
+    sig = torch.tensor([0.01, 0.03, 0.08, 0.12, 0.1414, 0.1415, 0.2, 0.5, 1.0, 2.5, 5.0, 0.05], dtype=torch.float32)
+    x0 = torch.rand(sig.numel(), 1, 9, 9, generator=g)
+    z = torch.randn(sig.numel(), 1, 9, 9, generator=g)
+    x = cube.reflect(x0 + sig[:, None, None, None] * z)
+    out.update(hk_sigma=sig.numpy(), hk_x=x.numpy(), hk_x0=x0.numpy(), hk_score=cube.score_hk(x, x0, sig).numpy())
+    out.update(hk_ef_only=cube._score_hk_ef(x, x0, sig ** 2 / 2).numpy(),
+               hk_refl_only=cube._score_hk_refl(x, x0, sig ** 2 / 2, refls=10).numpy())
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    t = torch.tensor([1e-5, 1e-3, 0.1, 0.4263, 0.5, 0.9, 1.0], dtype=torch.float32)
+    xz = torch.zeros(t.numel(), 1, 9, 9)
+    out.update(sde_t=t.numpy(), sde_sigma=sde.marginal_prob(xz, t)[1].numpy(), sde_g=sde.sde(xz, t)[1].numpy(),
+               ts_1000=torch.linspace(sde.T, 1e-5, 1000).numpy(), ts_10=torch.linspace(sde.T, 1e-5, 10).numpy())
+    save('cube_sde.npz', **out)
+
+
+TAPS = ['input_conv', 'down_blocks.0', 'down_attn.0', 'down_blocks.1', 'downsample.0', 'down_blocks.2',
+        'down_blocks.3', 'downsample.1', 'down_blocks.5', 'mid_block1', 'mid_block2', 'up_blocks.0', 'up_blocks.2',
+        'upsample.0', 'up_blocks.3', 'up_blocks.5', 'upsample.1', 'up_blocks.6', 'up_attn.6', 'up_blocks.8',
+        'up_attn.8']
+
+
+def gen_forward():
+    cfg = make_cfg()
+    model, params = ref_model(cfg)
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    g = torch.Generator().manual_seed(21)
+    B = 8
+    x = torch.rand(B, 1, 9, 9, generator=g)
+    t = torch.tensor([1e-5, 0.1, 0.4262, 0.4264, 0.7, 0.9, 0.999, 1.0], dtype=torch.float32)
+    labels = torch.rand(B, 1, generator=g)
+    taps = {}
+    mods = dict(model.named_modules())
+    hooks = [mods[n].register_forward_hook(lambda m, i, o, n=n: taps.__setitem__(n, o[:2].detach().numpy().copy()))
+             for n in TAPS]
+    with torch.no_grad():
+        score = mutils.get_score_fn(sde, model)(x, t, class_labels=labels)
+    for h in hooks:
+        h.remove()
+    with torch.no_grad():
+        temb = model.time_mlp(model.time_embed(torch.log(sde.marginal_prob(x, t)[1]))) + model.label_emb(labels)
+        cf0 = mutils.get_cf_score_fn(sde, model, labels, 0.0)(x, t)
+        cfn = mutils.get_cf_score_fn(sde, model, labels, None)(x, t)
+        wt = torch.linspace(-0.5, 3.0, B)
+        cfw = mutils.get_cf_score_fn(sde, model, labels, wt)(x, t)
+        model_out = mutils.get_model_fn(model)(x, sde.marginal_prob(x, t)[1], class_labels=labels)
+    assert torch.equal(model_out, score)
+    save('forward_9x9.npz', x=x.numpy(), t=t.numpy(), labels=labels.numpy(), score=score.numpy(), temb=temb.numpy(),
+         cf_w0=cf0.numpy(), cf_none=cfn.numpy(), cf_wt=cfw.numpy(), wt=wt.numpy(),
+         params_sha256=np.frombuffer(bytes.fromhex(W.params_sha256(params)), np.uint8),
+         **{'tap.' + k: v for k, v in taps.items()})
+    # 8x9 variant (BASELINE.json's named shape): image_size stays 9 so attention is kept
+    x89 = torch.rand(4, 1, 8, 9, generator=g)
+    t89 = torch.tensor([0.05, 0.3, 0.6, 1.0], dtype=torch.float32)
+    l89 = torch.rand(4, 1, generator=g)
+    with torch.no_grad():
+        s89 = mutils.get_score_fn(sde, model)(x89, t89, class_labels=l89)
+    save('forward_8x9.npz', x=x89.numpy(), t=t89.numpy(), labels=l89.numpy(), score=s89.numpy())
+
+
+class Recorder:
+    """Records every torch.rand / torch.randn_like the reference sampler draws."""
+
+    def __init__(self):
+        self.rand, self.randn = [], []
+        self._rand, self._randn_like = torch.rand, torch.randn_like
+
+    def __enter__(self):
+        def rand(*a, **k):
+            v = self._rand(*a, **k); self.rand.append(v.numpy().copy()); return v
+
+        def randn_like(x, **k):
+            v = self._randn_like(x, **k); self.randn.append(v.numpy().copy()); return v
+        torch.rand, torch.randn_like = rand, randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn_like = self._rand, self._randn_like
+
+
+def gen_sampler():
+    out = {}
+    B, N = 8, 10
+    g = torch.Generator().manual_seed(31)
+    labels = torch.rand(B, 1, generator=g)
+    wt = torch.linspace(0.0, 2.0, B)
+    cases = [('none_w0', 'none', labels, 0.0), ('langevin_w0', 'langevin', labels, 0.0),
+             ('none_wt', 'none', labels, wt), ('langevin_none', 'langevin', labels, None)]
+    # (class_labels=None is not a runnable case: with conditional=True the reference calls label_emb(None))
+    for tag, corr, lab, w in cases:
+        cfg = make_cfg(corrector=corr, num_scales=N)
+        model, _ = ref_model(cfg)
+        sde = sde_lib.RVESDE(0.01, 5, N=N)
+        fn = sampling.get_sampling_fn(cfg, sde, (B, 1, 9, 9), 1e-5, 'cpu')
+        # trace per-update x by wrapping the predictor's reflect-returning update
+        steps = []
+        pred_cls = sampling.get_predictor('euler_maruyama')
+        orig = pred_cls.update_fn
+
+        def traced(self, x, t, _o=orig):
+            r = _o(self, x, t); steps.append(r[0].numpy().copy()); return r
+        pred_cls.update_fn = traced
+        torch.manual_seed(1234)
+        with Recorder() as rec:
+            x, nfe = fn(model, weight=w, class_labels=lab)
+        pred_cls.update_fn = orig
+        assert len(rec.rand) == 2 and len(steps) == N - 1
+        out[f'{tag}.prior'] = rec.rand[1]
+        out[f'{tag}.noises'] = np.stack(rec.randn)
+        out[f'{tag}.steps'] = np.stack(steps)
+        out[f'{tag}.x'] = x.numpy()
+        out[f'{tag}.nfe'] = np.int64(nfe)
+        assert np.array_equal(steps[-1], x.numpy())
+    out['labels'] = labels.numpy(); out['wt'] = wt.numpy()
+    save('sampler_10step.npz', **out)
+
+
+def gen_train():
+    """One score-matching step with dropout=0 and cond_drop_prob=0 so the loss is a pure function of (t, z)."""
+    cfg = make_cfg(dropout=0.0, cond_drop_prob=0.0)
+    model, _ = ref_model(cfg)
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    B = 8
+    g = torch.Generator().manual_seed(41)
+    batch = torch.rand(B, 1, 9, 9, generator=g)
+    labels = torch.rand(B, 1, generator=g)
+    optimizer = losses.get_optimizer(cfg, model.parameters())
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=optimizer, model=model, ema=ema, step=0, scaler=None)
+    optimize_fn = losses.optimization_manager(cfg)
+    train_step = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=False,
+                                    likelihood_weighting=False)
+    eval_step = losses.get_step_fn(sde, train=False, optimize_fn=optimize_fn, reduce_mean=False,
+                                   likelihood_weighting=False)
+    out = dict(batch=batch.numpy(), labels=labels.numpy())
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    # make t straddle the score_hk switch (sde-time 0.4263) deterministically
+    tvals = torch.tensor([0.02, 0.2, 0.41, 0.43, 0.6, 0.8, 0.95, 0.999], dtype=torch.float32)
+    _rand = torch.rand
+    torch.rand = lambda *a, **k: ((tvals - 1e-5) / (1 - 1e-5)).clone() if a and a[0] == B else _rand(*a, **k)
+    try:
+        for step in range(2):
+            torch.manual_seed(77 + step)
+            with Recorder() as rec:
+                # Recorder wraps the patched rand above; randn_like gives z
+                loss = train_step(state, batch, class_labels=labels)
+            out[f'step{step}.t'] = (rec.rand[0] * (1 - 1e-5) + 1e-5).astype(np.float32)
+            out[f'step{step}.z'] = rec.randn[0]
+            out[f'step{step}.loss'] = loss.detach().numpy()
+            if step == 0:
+                gn = np.array([float(p.grad.norm()) for n, p in model.named_parameters() if p.requires_grad], np.float32)
+                out['step0.grad_norms'] = gn          # AFTER clip_grad_norm_(0.5) (losses.py:39-40)
+                for n in ['out_conv.weight', 'time_mlp.0.bias', 'down_blocks.0.Conv_0.bias', 'up_attn.8.NIN_3.W',
+                          'label_emb.weight']:
+                    out['step0.grad.' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
+        torch.manual_seed(99)
+        with Recorder() as rec:
+            ev = eval_step(state, batch, class_labels=labels)
+        out['eval.t'] = (rec.rand[0] * (1 - 1e-5) + 1e-5).astype(np.float32)
+        out['eval.z'] = rec.randn[0]
+        out['eval.loss'] = ev.numpy()
+    finally:
+        torch.rand = _rand
+    out['after2.out_conv.bias'] = model.out_conv.bias.detach().numpy().copy()
+    out['after2.time_mlp.0.bias'] = model.time_mlp[0].bias.detach().numpy().copy()
+    out['after2.ema.out_conv.bias'] = ema.shadow_params[-1].numpy().copy()
+    out['param_names'] = np.array(names)
+    save('train_step.npz', **out)
+
+
+def gen_init():
+    """Reference init under torch.manual_seed(0): lets the build's parameter shell prove it consumes the torch RNG
+    identically (same construction order)."""
+    torch.manual_seed(0)
+    model = mutils.create_model(make_cfg())
+    sd = model.state_dict()
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode()); h.update(v.numpy().tobytes())
+    save('init_seed0.npz', sha256=np.frombuffer(h.digest(), np.uint8), names=np.array(list(sd.keys())),
+         **{'v.' + k: sd[k].numpy().reshape(-1)[:4].copy() for k in
+            ['time_embed.W', 'time_mlp.2.weight', 'label_emb.bias', 'input_conv.weight', 'down_blocks.2.NIN_0.W',
+             'down_attn.1.NIN_3.W', 'up_blocks.6.Dense_0.weight', 'upsample.1.Conv_0.weight', 'out_conv.weight']})
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    gen_cube_sde()
+    gen_forward()
+    gen_sampler()
+    gen_train()
+    gen_init()

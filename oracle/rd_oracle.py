@@ -1,0 +1,399 @@
+"""CPU oracle for the Reflected-Diffusion hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a plain-numpy fp32 restatement of the reference's algorithm for the
+path named in BASELINE.json: the NCSN++ score network forward, the RVESDE
+schedule, cube.reflect / score_hk, the classifier-free-guidance score adapter,
+the reflected Euler-Maruyama predictor, the reflected Langevin corrector, the
+PC sampling loop and the score-matching loss.
+
+It is NOT part of the product: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import it.  The product path (rdmi + librdmi.so)
+never routes through this file and fails loudly when the HIP library is absent.
+
+Parity pinning: every function here is checked against outputs of the reference
+itself (imported from /root/reference in the build container by
+oracle/gen_golden.py) via the fixtures committed in tests/golden/*.npz -- see
+tests/test_oracle_golden.py.  The reference ships no tests or known-answer
+vectors of its own, so those generated fixtures are the pin.
+
+Citations are relative to /root/reference/Reflected-Diffusion ("RD/").
+All arithmetic is float32 unless a line says otherwise.
+"""
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# cube.py
+# --------------------------------------------------------------------------
+def reflect(x):
+    """RD/cube.py:34-49 -- floor-mod 2 then fold (1,2) back onto (0,1)."""
+    x = np.asarray(x, dtype=F32)
+    m = np.mod(x, F32(2.0)).astype(F32)          # python-style modulo: result in [0, 2)
+    return np.where(m > 1, F32(2.0) - m, m).astype(F32)
+
+
+def inside(x):
+    """RD/cube.py:17-31."""
+    x = np.asarray(x).reshape(x.shape[0], -1)
+    return np.logical_and(x >= 0, x <= 1).all(axis=-1)
+
+
+def _bcast(v, like):
+    return np.asarray(v, dtype=F32).reshape(v.shape + (1,) * (like.ndim - v.ndim))
+
+
+def score_hk_ef(x, x_orig, t, efs=20):
+    """RD/cube.py:73-107 -- eigenfunction (cosine series) form, k = 1..efs."""
+    x = np.asarray(x, F32); x_orig = np.asarray(x_orig, F32); t = np.asarray(t, F32)
+    k = np.arange(1, efs + 1, dtype=F32)
+    kk = k.reshape((efs,) + (1,) * x.ndim)
+    pi = F32(math.pi)
+    xr = (pi * x[None]) * kk
+    xo = (pi * x_orig[None]) * kk
+    x_sin, x_cos, xo_cos = np.sin(xr), np.cos(xr), np.cos(xo)
+    # (-t * k^2 * pi^2).exp() with t:[B] -> [efs, B]
+    e_den = np.exp((-t[None, :] * (k[:, None] ** 2)) * F32(math.pi ** 2)).astype(F32)
+    e_num = e_den * k[:, None]
+    e_den_b = e_den.reshape(e_den.shape + (1,) * (x.ndim - 1))
+    e_num_b = e_num.reshape(e_num.shape + (1,) * (x.ndim - 1))
+    num = F32(-2 * math.pi) * (e_num_b * (x_sin * xo_cos)).sum(0, dtype=F32)
+    den = F32(1) + F32(2) * (e_den_b * (x_cos * xo_cos)).sum(0, dtype=F32)
+    return (num / (den + F32(1e-12))).astype(F32)
+
+
+def score_hk_refl(x, x_orig, t, refls=10):
+    """RD/cube.py:110-146 -- method of images, j = -refls..refls step 1 of (2j +/- x)."""
+    x = np.asarray(x, F32); x_orig = np.asarray(x_orig, F32); t = np.asarray(t, F32)
+    r = np.arange(-2 * refls, 2 * refls + 1, 2, dtype=F32)
+    rr = r.reshape((r.size,) + (1,) * x.ndim)
+    x_refl = np.concatenate([rr + x[None], rr - x[None]], axis=0)
+    sign = np.concatenate([np.ones_like(r), -np.ones_like(r)]).reshape((2 * r.size,) + (1,) * x.ndim)
+    xm = x_refl - x_orig[None]
+    fourt = F32(4) * _bcast(t, x)[None]
+    coeff = F32(-2) * xm / fourt
+    e = np.exp(-(xm ** 2) / fourt).astype(F32)
+    num = (coeff * e * sign).sum(0, dtype=F32)
+    den = e.sum(0, dtype=F32)
+    return (num / (den + F32(1e-12))).astype(F32)
+
+
+def score_hk(x, x_orig, sigma, efs=20, refls=10, min_cutoff=1e-2):
+    """RD/cube.py:149-193 -- per-sample switch on t = sigma^2/2 > min_cutoff."""
+    x = np.asarray(x, F32); x_orig = np.asarray(x_orig, F32)
+    sigma = np.asarray(sigma, F32)
+    if sigma.ndim == 0:
+        sigma = np.full((x.shape[0],), sigma, F32)
+    t = (sigma ** 2 / F32(2)).astype(F32)
+    ef = t > F32(min_cutoff)
+    out = np.zeros_like(x)
+    if ef.any():
+        out[ef] = score_hk_ef(x[ef], x_orig[ef], t[ef], efs)
+    if (~ef).any():
+        out[~ef] = score_hk_refl(x[~ef], x_orig[~ef], t[~ef], refls)
+    return out
+
+
+# --------------------------------------------------------------------------
+# sde_lib.py : RVESDE
+# --------------------------------------------------------------------------
+class RVESDE:
+    """RD/sde_lib.py:114-161."""
+
+    def __init__(self, sigma_min=0.01, sigma_max=50, N=1000, T=1):
+        self.sigma_min, self.sigma_max, self.N, self.T = sigma_min, sigma_max, N, T
+
+    def sigma(self, t):
+        t = np.asarray(t, F32)
+        # torch: python_float ** float32 tensor -> float32 pow
+        return (F32(self.sigma_min) * np.power(F32(self.sigma_max / self.sigma_min), t)).astype(F32)
+
+    def marginal_prob(self, x, t):            # :142-145
+        return x, self.sigma(t)
+
+    def g(self, t):                           # :135-140 (diffusion coefficient)
+        c = F32(math.sqrt(2 * (math.log(self.sigma_max) - math.log(self.sigma_min))))
+        return (self.sigma(t) * c).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# models/layers.py, models/layerspp.py
+# --------------------------------------------------------------------------
+def silu(x):
+    return (x / (F32(1) + np.exp(-x))).astype(F32)
+
+
+def linear(x, w, b):
+    """nn.Linear: w is [out, in]."""
+    return (x @ w.T + b).astype(F32)
+
+
+def group_norm(x, gamma, beta, eps=1e-6):
+    """nn.GroupNorm(min(C//4, 32), C, eps=1e-6): RD/models/layerspp.py:72,178,184."""
+    B, C = x.shape[:2]
+    G = min(C // 4, 32)
+    xg = x.reshape(B, G, -1)
+    mean = xg.mean(-1, keepdims=True, dtype=F32)
+    var = ((xg - mean) ** 2).mean(-1, keepdims=True, dtype=F32)
+    y = ((xg - mean) / np.sqrt(var + F32(eps))).reshape(x.shape)
+    return (y * gamma.reshape(1, C, 1, 1) + beta.reshape(1, C, 1, 1)).astype(F32)
+
+
+def conv3x3(x, w, b, stride=1, padding=1):
+    """RD/models/layers.py:103-109 -- nn.Conv2d(k=3), weights OIHW; im2col + one GEMM."""
+    B, C, H, W = x.shape
+    O = w.shape[0]
+    if padding:
+        x = np.pad(x, ((0, 0), (0, 0), (padding, padding), (padding, padding)))
+    Hp, Wp = x.shape[2:]
+    Ho, Wo = (Hp - 3) // stride + 1, (Wp - 3) // stride + 1
+    cols = np.empty((B, Ho, Wo, 9, C), F32)
+    for dy in range(3):
+        for dx in range(3):
+            v = x[:, :, dy:dy + (Ho - 1) * stride + 1:stride, dx:dx + (Wo - 1) * stride + 1:stride]
+            cols[:, :, :, dy * 3 + dx, :] = v.transpose(0, 2, 3, 1)
+    wm = w.transpose(2, 3, 1, 0).reshape(9 * C, O)           # [(tap, c), o]
+    y = cols.reshape(B * Ho * Wo, 9 * C) @ wm + b
+    return y.reshape(B, Ho, Wo, O).transpose(0, 3, 1, 2).astype(F32)
+
+
+def nin(x, W, b):
+    """RD/models/layers.py:531-540 -- channel matmul, W is [in, out]."""
+    y = np.einsum('bchw,co->bohw', x, W, optimize=True) + b.reshape(1, -1, 1, 1)
+    return y.astype(F32)
+
+
+def nearest_resize(x, Ho, Wo):
+    """F.interpolate(mode='nearest'): src = floor(dst * in / out)."""
+    H, W = x.shape[2:]
+    iy = np.floor(np.arange(Ho) * (H / Ho)).astype(np.int64)
+    ix = np.floor(np.arange(Wo) * (W / Wo)).astype(np.int64)
+    return x[:, :, iy][:, :, :, ix]
+
+
+def fourier_embed(log_sigma, W):
+    """RD/models/layerspp.py:26-28."""
+    xp = (log_sigma[:, None] * W[None, :]) * F32(2) * F32(np.pi)
+    return np.concatenate([np.sin(xp), np.cos(xp)], axis=-1).astype(F32)
+
+
+def attn_block(p, pre, x):
+    """AttnBlockpp, RD/models/layerspp.py:80-96 (skip_rescale=True)."""
+    B, C, H, W = x.shape
+    h = group_norm(x, p[pre + 'GroupNorm_0.weight'], p[pre + 'GroupNorm_0.bias'])
+    q = nin(h, p[pre + 'NIN_0.W'], p[pre + 'NIN_0.b']).reshape(B, C, H * W)
+    k = nin(h, p[pre + 'NIN_1.W'], p[pre + 'NIN_1.b']).reshape(B, C, H * W)
+    v = nin(h, p[pre + 'NIN_2.W'], p[pre + 'NIN_2.b']).reshape(B, C, H * W)
+    w = np.einsum('bcq,bck->bqk', q, k, optimize=True) * F32(int(C) ** (-0.5))
+    w = w - w.max(-1, keepdims=True)
+    w = np.exp(w); w = (w / w.sum(-1, keepdims=True, dtype=F32)).astype(F32)
+    h = np.einsum('bqk,bck->bcq', w, v, optimize=True).reshape(B, C, H, W).astype(F32)
+    h = nin(h, p[pre + 'NIN_3.W'], p[pre + 'NIN_3.b'])
+    return ((x + h) / F32(np.sqrt(2.))).astype(F32)
+
+
+def resblock(p, pre, x, temb_act, drop_mask=None, drop_p=0.0):
+    """ResnetBlockDDPMpp, RD/models/layerspp.py:199-214 (skip_rescale=True).
+
+    temb_act is SiLU(temb) (the block applies act() to temb before Dense_0, :202).
+    drop_mask: optional keep-mask (1=keep) for Dropout_0 in train mode."""
+    h = silu(group_norm(x, p[pre + 'GroupNorm_0.weight'], p[pre + 'GroupNorm_0.bias']))
+    h = conv3x3(h, p[pre + 'Conv_0.weight'], p[pre + 'Conv_0.bias'])
+    h = h + linear(temb_act, p[pre + 'Dense_0.weight'], p[pre + 'Dense_0.bias'])[:, :, None, None]
+    h = silu(group_norm(h, p[pre + 'GroupNorm_1.weight'], p[pre + 'GroupNorm_1.bias']))
+    if drop_mask is not None:
+        h = (h * drop_mask / F32(1.0 - drop_p)).astype(F32)
+    h = conv3x3(h, p[pre + 'Conv_1.weight'], p[pre + 'Conv_1.bias'])
+    if (pre + 'NIN_0.W') in p:
+        x = nin(x, p[pre + 'NIN_0.W'], p[pre + 'NIN_0.b'])
+    return ((x + h) / F32(np.sqrt(2.))).astype(F32)
+
+
+DEFAULT_ARCH = dict(nf=64, ch_mult=(1, 2, 2), num_res_blocks=2, attn_resolutions=(9,), image_size=9)
+
+
+def ncsnpp_forward(p, x, sigma, labels, arch=DEFAULT_ARCH, taps=None, drop_masks=None, drop_p=0.0):
+    """NCSNpp.forward in eval mode, RD/models/ncsnpp.py:226-354.
+
+    p: dict of fp32 arrays under the reference's state-dict names.
+    x [B,C,H,W], sigma [B] (time_cond), labels [B,num_classes].
+    taps: optional dict that receives named intermediate activations."""
+    x = np.asarray(x, F32); sigma = np.asarray(sigma, F32); labels = np.asarray(labels, F32)
+    ch_mult, nrb = arch['ch_mult'], arch['num_res_blocks']
+    nlev = len(ch_mult)
+    attn_at = [arch['image_size'] // (2 ** i) in arch['attn_resolutions'] for i in range(nlev)]
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+
+    def dm(name):
+        return None if drop_masks is None else drop_masks[name]
+
+    temb = fourier_embed(np.log(sigma), p['time_embed.W'])                      # :252
+    temb = linear(temb, p['time_mlp.0.weight'], p['time_mlp.0.bias'])
+    temb = linear(silu(temb), p['time_mlp.2.weight'], p['time_mlp.2.bias'])      # :257
+    temb = temb + linear(labels, p['label_emb.weight'], p['label_emb.bias'])     # :262
+    tap('temb', temb)
+    ta = silu(temb)
+
+    h = conv3x3(x, p['input_conv.weight'], p['input_conv.bias'])                 # :266
+    tap('input_conv', h)
+    hs = [h]
+    d = 0
+    for i in range(nlev):                                                        # :273-292
+        for _ in range(nrb):
+            h = resblock(p, f'down_blocks.{d}.', h, ta, dm(f'down_blocks.{d}'), drop_p)
+            tap(f'down_blocks.{d}', h)
+            if attn_at[i]:
+                h = attn_block(p, f'down_attn.{d}.', h)
+                tap(f'down_attn.{d}', h)
+            hs.append(h)
+            d += 1
+        hs.append(h)
+        if i != nlev - 1:                                                        # Downsample: layerspp.py:157-159
+            hp = np.pad(h, ((0, 0), (0, 0), (0, 1), (0, 1)))
+            h = conv3x3(hp, p[f'downsample.{i}.Conv_0.weight'], p[f'downsample.{i}.Conv_0.bias'], stride=2, padding=0)
+            tap(f'downsample.{i}', h)
+    h = resblock(p, 'mid_block1.', h, ta, dm('mid_block1'), drop_p)              # :297-302
+    tap('mid_block1', h)
+    h = resblock(p, 'mid_block2.', h, ta, dm('mid_block2'), drop_p)
+    tap('mid_block2', h)
+    u = 0
+    for i in range(nlev):                                                        # :311-338
+        lev = nlev - 1 - i
+        for _ in range(nrb + 1):
+            skip = hs.pop()
+            if h.shape[2:] != skip.shape[2:]:
+                h = nearest_resize(h, *skip.shape[2:])                           # :319-320
+            h = np.concatenate([h, skip], axis=1)
+            h = resblock(p, f'up_blocks.{u}.', h, ta, dm(f'up_blocks.{u}'), drop_p)
+            tap(f'up_blocks.{u}', h)
+            if attn_at[lev]:
+                h = attn_block(p, f'up_attn.{u}.', h)
+                tap(f'up_attn.{u}', h)
+            u += 1
+        if i != nlev - 1:                                                        # Upsample: layerspp.py:122-124
+            H, W = h.shape[2:]
+            h = nearest_resize(h, 2 * H, 2 * W)
+            h = conv3x3(h, p[f'upsample.{i}.Conv_0.weight'], p[f'upsample.{i}.Conv_0.bias'])
+            tap(f'upsample.{i}', h)
+    h = silu(group_norm(h, p['out_norm.weight'], p['out_norm.bias']))            # :343-347
+    h = conv3x3(h, p['out_conv.weight'], p['out_conv.bias'])
+    return h
+
+
+# --------------------------------------------------------------------------
+# models/utils.py : score adapters
+# --------------------------------------------------------------------------
+def score_fn(p, sde, x, t, labels, arch=DEFAULT_ARCH):
+    """get_score_fn, RD/models/utils.py:87-105 (scale_by_sigma=False)."""
+    return ncsnpp_forward(p, x, sde.sigma(t), labels, arch)
+
+
+def cf_score_fn(p, sde, x, t, labels, weight, arch=DEFAULT_ARCH):
+    """get_cf_score_fn, RD/models/utils.py:108-140: one forward at 2B, then combine."""
+    B = x.shape[0]
+    xx = np.concatenate([x, x], 0)
+    tt = np.concatenate([t, t], 0)
+    ll = np.concatenate([labels, np.zeros_like(labels)], 0)
+    s = score_fn(p, sde, xx, tt, ll, arch)
+    if weight is None:
+        w = np.zeros((B,), F32)
+    elif np.isscalar(weight):
+        w = np.full((B,), float(weight), F32)
+    else:
+        w = np.asarray(weight, F32)
+    w = w.reshape(-1, 1, 1, 1)
+    return ((F32(1) + w) * s[:B] - w * s[B:]).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# sampling.py : predictor / corrector / PC loop
+# --------------------------------------------------------------------------
+def em_predictor_update(sde, score, x, t, z):
+    """ReflectedEulerMaruyamaPredictor.update_fn, RD/sampling.py:198-207 with
+    RSDE.sde (RD/sde_lib.py:93-101): drift = -g^2 * score, dt = -1/N."""
+    dt = -1.0 / sde.N
+    g = sde.g(t)
+    drift = (np.zeros_like(x) - (g[:, None, None, None] ** 2) * score * F32(1.0)).astype(F32)
+    x_mean = (x + drift * F32(dt)).astype(F32)
+    x_new = (x_mean + (g[:, None, None, None] * F32(np.sqrt(-dt))) * z).astype(F32)
+    return reflect(x_new), reflect(x_mean)
+
+
+def langevin_update(score, x, z, snr):
+    """One inner step of ReflectedLangevinCorrector.update_fn, RD/sampling.py:222-231."""
+    B = x.shape[0]
+    gn = np.sqrt((score.reshape(B, -1) ** 2).sum(-1, dtype=F32)).mean(dtype=F32)
+    nn_ = np.sqrt((z.reshape(B, -1) ** 2).sum(-1, dtype=F32)).mean(dtype=F32)
+    step = ((F32(snr) * nn_ / gn) ** 2 * F32(2)).astype(F32)
+    x_mean = (x + step * score).astype(F32)
+    x_new = (x_mean + np.sqrt(step * F32(2)) * z).astype(F32)
+    return reflect(x_new), reflect(x_mean)
+
+
+def pc_sampler(p, sde, prior, noises, labels, weight, eps=1e-5, snr=0.01, n_steps=1,
+               corrector='none', arch=DEFAULT_ARCH, trace=None, teacher=None):
+    """get_pc_sampler/pc_sampler, RD/sampling.py:292-339, with the prior (the SECOND
+    torch.rand draw, :324) and every per-update randn_like tensor injected:
+    noises[k] in consumption order (corrector inner steps first, then predictor).
+    Reproduces F5: N-1 updates, the denoiser result is dropped, noisy x is returned.
+    teacher: optional recorded per-update states; when given, update i+1 starts from teacher[i]
+    (the SDE map amplifies fp32 noise by g^2/N per update, so parity is checked per update)."""
+    x = np.asarray(prior, F32)
+    B = x.shape[0]
+    ts = torch_linspace(sde.T, eps, sde.N)                                        # RD/sampling.py:325
+    it = iter(noises)
+    for i in range(sde.N):
+        if i >= sde.N - 1:
+            break
+        t = np.full((B,), ts[i], F32)
+
+        def sf(xx):
+            if labels is None:
+                return score_fn(p, sde, xx, t, None, arch)
+            return cf_score_fn(p, sde, xx, t, labels, weight, arch)
+
+        if corrector == 'langevin':
+            for _ in range(n_steps):
+                x, _ = langevin_update(sf(x), x, next(it), snr)
+        elif corrector != 'none':
+            raise KeyError(corrector)
+        x, x_mean = em_predictor_update(sde, sf(x), x, t, next(it))
+        if trace is not None:
+            trace.append(x.copy())
+        if teacher is not None:                 # teacher forcing: restart each update from the recorded state
+            x = np.asarray(teacher[i], F32)
+    return x, sde.N * (n_steps + 1)
+
+
+def torch_linspace(start, end, steps):
+    """torch.linspace(fp32): step = (end-start)/(steps-1) in fp32; element i is
+    fma(step, i, start) for the first half and fma(-step, steps-1-i, end) for the second
+    (single rounding; verified bit-exact against torch in tests/golden/cube_sde.npz)."""
+    start, end = F32(start), F32(end)
+    step = float(F32((end - start) / F32(steps - 1)))
+    i = np.arange(steps)
+    lo = float(start) + step * i
+    hi = float(end) - step * (steps - 1 - i)
+    return np.where(i < steps // 2, lo, hi).astype(F32)
+
+
+# --------------------------------------------------------------------------
+# losses.py : score-matching loss (training), evaluated with injected t, z
+# --------------------------------------------------------------------------
+def sde_loss(p, sde, batch, labels, t, z, arch=DEFAULT_ARCH, drop_masks=None, drop_p=0.0):
+    """get_sde_loss_fn/loss_fn, RD/losses.py:68-93 with reduce_mean=False,
+    likelihood_weighting=False (the shipped config).  Returns (loss, score, target, perturbed)."""
+    batch = np.asarray(batch, F32)
+    std = sde.sigma(t)
+    perturbed = reflect(batch + std[:, None, None, None] * z)
+    score = ncsnpp_forward(p, perturbed, std, labels, arch, drop_masks=drop_masks, drop_p=drop_p)
+    target = score_hk(perturbed, batch, std)
+    losses = (std ** 2)[:, None, None, None] * (score - target) ** 2
+    per = F32(0.5) * losses.reshape(losses.shape[0], -1).sum(-1, dtype=F32)
+    return per.mean(dtype=F32), score, target, perturbed

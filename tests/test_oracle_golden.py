@@ -1,0 +1,97 @@
+"""Pins the numpy oracle (oracle/rd_oracle.py) against fixtures recorded from the REFERENCE itself
+(oracle/gen_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import rd_oracle as O
+from oracle.weights import make_params, param_specs, params_sha256
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_reflect_known_answers(golden):
+    g = golden('cube_sde.npz')
+    # SURVEY 8a-A1 table
+    close(O.reflect(np.array([-2.3, -1.2, -0.3, 1.2, 2.3, 3.7, 1, -1, 2, 0], np.float32)),
+          np.array([0.3, 0.8, 0.3, 0.8, 0.3, 0.3, 1, 1, 0, 0], np.float32), atol=1e-6)
+    assert np.array_equal(O.reflect(g['reflect_known_in']), g['reflect_known_out'])
+    assert np.array_equal(O.reflect(g['reflect_rand_in']), g['reflect_rand_out'])
+
+
+def test_score_hk(golden):
+    g = golden('cube_sde.npz')
+    t = g['hk_sigma'] ** 2 / 2
+    close(O.score_hk_ef(g['hk_x'], g['hk_x0'], t), g['hk_ef_only'], rtol=2e-4, atol=1e-4)
+    close(O.score_hk_refl(g['hk_x'], g['hk_x0'], t), g['hk_refl_only'], rtol=2e-4, atol=1e-3)
+    close(O.score_hk(g['hk_x'], g['hk_x0'], g['hk_sigma']), g['hk_score'], rtol=2e-4, atol=1e-3)
+
+
+def test_sde_schedule(golden):
+    g = golden('cube_sde.npz')
+    sde = O.RVESDE(0.01, 5, N=1000)
+    close(sde.sigma(g['sde_t']), g['sde_sigma'], rtol=1e-6, atol=0)
+    close(sde.g(g['sde_t']), g['sde_g'], rtol=1e-6, atol=0)
+    assert np.array_equal(O.torch_linspace(1, 1e-5, 1000), g['ts_1000'])
+    assert np.array_equal(O.torch_linspace(1, 1e-5, 10), g['ts_10'])
+
+
+def test_param_recipe(golden, params0):
+    g = golden('forward_9x9.npz')
+    assert bytes(g['params_sha256']).hex() == params_sha256(params0)
+    assert len(param_specs()) == 261
+    assert sum(int(np.prod(s)) for _, s in param_specs()) == 6254913
+    names = list(golden('init_seed0.npz')['names'])
+    assert [n for n, _ in param_specs()] == names
+
+
+def test_forward_9x9(golden, params0):
+    g = golden('forward_9x9.npz')
+    sde = O.RVESDE(0.01, 5, N=1000)
+    taps = {}
+    out = O.ncsnpp_forward(params0, g['x'], sde.sigma(g['t']), g['labels'], taps=taps)
+    close(taps['temb'], g['temb'], rtol=1e-4, atol=1e-4)
+    for k in g.files:
+        if k.startswith('tap.'):
+            close(taps[k[4:]][:2], g[k], rtol=1e-4, atol=1e-4)
+    close(out, g['score'], rtol=1e-4, atol=1e-4)
+    close(O.cf_score_fn(params0, sde, g['x'], g['t'], g['labels'], 0.0), g['cf_w0'], rtol=1e-4, atol=1e-4)
+    close(O.cf_score_fn(params0, sde, g['x'], g['t'], g['labels'], None), g['cf_none'], rtol=1e-4, atol=1e-4)
+    close(O.cf_score_fn(params0, sde, g['x'], g['t'], g['labels'], g['wt']), g['cf_wt'], rtol=1e-4, atol=2e-4)
+
+
+def test_forward_8x9(golden, params0):
+    g = golden('forward_8x9.npz')
+    sde = O.RVESDE(0.01, 5, N=1000)
+    close(O.score_fn(params0, sde, g['x'], g['t'], g['labels']), g['score'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('tag,corr,wkey', [('none_w0', 'none', 0.0), ('langevin_w0', 'langevin', 0.0),
+                                           ('none_wt', 'none', 'wt'), ('langevin_none', 'langevin', None)])
+def test_sampler_10step(golden, params0, tag, corr, wkey):
+    g = golden('sampler_10step.npz')
+    sde = O.RVESDE(0.01, 5, N=10)
+    w = g['wt'] if wkey == 'wt' else wkey
+    steps = g[f'{tag}.steps']
+    ts = O.torch_linspace(1, 1e-5, 10)
+    amp = np.maximum(1.0, sde.g(ts[:9]) ** 2 / 10)          # per-update amplification of a score error
+    trace = []
+    x, nfe = O.pc_sampler(params0, sde, g[f'{tag}.prior'], list(g[f'{tag}.noises']), g['labels'], w, eps=1e-5,
+                          snr=0.01, n_steps=1, corrector=corr, trace=trace, teacher=steps)
+    assert nfe == int(g[f'{tag}.nfe']) == 20
+    assert len(trace) == len(steps) == 9
+    for i, (a, b) in enumerate(zip(trace, steps)):
+        close(a, b, rtol=0, atol=2e-5 * amp[i])              # teacher-forced, per update
+    # free run: N=10 makes the first updates chaotic (x += 31*score), so only a loose (median) end-to-end bound
+    x, _ = O.pc_sampler(params0, sde, g[f'{tag}.prior'], list(g[f'{tag}.noises']), g['labels'], w, eps=1e-5,
+                        snr=0.01, n_steps=1, corrector=corr)
+    assert np.median(np.abs(x - g[f'{tag}.x'])) < 5e-3
+    assert x.min() >= 0 and x.max() <= 1
+
+
+def test_train_loss(golden, params0):
+    g = golden('train_step.npz')
+    sde = O.RVESDE(0.01, 5, N=1000)
+    loss, *_ = O.sde_loss(params0, sde, g['batch'], g['labels'], g['step0.t'], g['step0.z'])
+    close(loss, g['step0.loss'], rtol=2e-4, atol=0)
