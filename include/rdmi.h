@@ -1,0 +1,150 @@
+/* rdmi.h -- C ABI of librdmi.so: the MI355X-native (gfx950) NCSN++ score network and
+ * reflected predictor-corrector sampler.
+ *
+ * The reference (sriramelango/optimized-diffusion-model) is 100 % Python/PyTorch and has no
+ * FFI of its own; its boundary for this path is a set of Python closures.
+ * Each entry point below names the reference closure/method it sits under
+ * ("RD/" = Reflected-Diffusion/ in the reference tree).  The Python mirror of those
+ * closures lives in optimized-diffusion-model_amd/rdmi/ and binds these symbols with ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer to fp32 unless it
+ *    says "host"; tensors are dense, row-major, in the reference's own layouts
+ *    (x / score: [B, C=1, H, W]; labels: [B, num_classes]; sigma / t / weight: [B]).
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream); the caller keeps the buffers alive until the stream is synchronised.
+ *  - return value: 0 = ok, non-zero = error; rdmi_last_error() gives the message
+ *    (thread-local).  Nothing falls back to a CPU path.
+ */
+#ifndef RDMI_H
+#define RDMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDMI_MAX_LEVELS 8
+
+/* Architecture keys read by NCSNpp.__init__ (RD/models/ncsnpp.py:51-93). */
+typedef struct rdmi_arch {
+    int nf;                         /* config.model.nf                                  */
+    int n_levels;                   /* len(config.model.ch_mult)                        */
+    int ch_mult[RDMI_MAX_LEVELS];   /* config.model.ch_mult                             */
+    int num_res_blocks;             /* config.model.num_res_blocks                      */
+    int attn_levels;                /* bit i set <=> image_size // 2**i in attn_resolutions */
+    int channels;                   /* config.model.channels (1)                        */
+    int num_classes;                /* config.model.num_classes (label_emb fan-in)      */
+    int conditional;                /* config.model.conditional                         */
+    int scale_by_sigma;             /* config.model.scale_by_sigma                      */
+    float fourier_2pi_prescaled;    /* reserved, must be 0                              */
+} rdmi_arch;
+
+typedef struct rdmi_ctx rdmi_ctx;
+
+/* Create a context for model batches up to max_batch samples of H x W pixels on the current
+ * HIP device; allocates the activation workspace, packed-weight arena and launch plan.
+ * Replaces: NCSNpp.__init__ + .to(device) (RD/models/ncsnpp.py:42-224) for the compute side;
+ * parameters stay owned by the Python module (see rdmi_set_param). */
+int rdmi_create(const rdmi_arch* arch, int max_batch, int H, int W, rdmi_ctx** out);
+int rdmi_destroy(rdmi_ctx* ctx);
+
+/* Number of parameter tensors the context expects and the i-th one's reference state-dict
+ * name / element count (e.g. "down_blocks.2.NIN_0.W", 8192).  Order = the reference's
+ * registration order (what EMA and Adam iterate, RD/models/ema.py:28). */
+int rdmi_num_params(const rdmi_ctx* ctx);
+int rdmi_param_info(const rdmi_ctx* ctx, int index, const char** name, size_t* numel);
+
+/* Bind a parameter by its reference state-dict name to a BORROWED device pointer in the
+ * reference's layout (conv OIHW, Linear [out,in], NIN.W [in,out]).  No copy is kept in that
+ * layout: EMA copy_to/restore and optimizer steps written through the same storage are seen by
+ * the next call.  Replaces nn.Module parameter registration. */
+int rdmi_set_param(rdmi_ctx* ctx, const char* name, const float* dev_ptr, size_t numel);
+
+/* Re-read every bound parameter into the kernels' packed MFMA layout (one launch).  Called by
+ * the entry points below unless RDMI_PARAMS_CACHED is passed. */
+int rdmi_repack(rdmi_ctx* ctx, void* stream);
+
+#define RDMI_PARAMS_CACHED 1u   /* caller guarantees parameters are unchanged since the last call */
+
+/* out[B,1,H,W] = NCSNpp.forward(x, time_cond=sigma, class_labels=labels) in eval mode.
+ * Replaces: model_fn of get_model_fn (RD/models/utils.py:66-82) -> NCSNpp.forward
+ * (RD/models/ncsnpp.py:226-354).  labels may be NULL only if arch.conditional == 0. */
+int rdmi_forward(rdmi_ctx* ctx, const float* x, const float* sigma, const float* labels, float* out,
+                 int B, unsigned flags, void* stream);
+
+/* score = model(x, sigma(t), labels) with sigma(t) = sigma_min*(sigma_max/sigma_min)^t.
+ * Replaces: score_fn of get_score_fn (RD/models/utils.py:100-103) + RVESDE.marginal_prob
+ * (RD/sde_lib.py:142-145). */
+int rdmi_score(rdmi_ctx* ctx, const float* x, const float* t, const float* labels, float* out, int B,
+               double sigma_min, double sigma_max, unsigned flags, void* stream);
+
+/* Classifier-free-guidance score: one forward at 2B ([x;x], [t;t], [labels;0]) then
+ * (1+w)*s_cond - w*s_uncond.  weight: device [B] or NULL (=0).
+ * Replaces: weighted_score_fn of get_cf_score_fn (RD/models/utils.py:120-138). */
+int rdmi_cf_score(rdmi_ctx* ctx, const float* x, const float* t, const float* labels, const float* weight,
+                  float* out, int B, double sigma_min, double sigma_max, unsigned flags, void* stream);
+
+/* cube.reflect (RD/cube.py:34-49), elementwise, in == out allowed. */
+int rdmi_reflect(const float* in, float* out, size_t n, void* stream);
+
+/* cube.score_hk (RD/cube.py:149-193): score of the reflected heat kernel started at x_orig with
+ * std sigma[B]; per-sample switch between the eigenfunction series and the image sum. */
+int rdmi_score_hk(const float* x, const float* x_orig, const float* sigma, float* out, int B, int elems_per_sample,
+                  int efs, int refls, float min_cutoff, void* stream);
+
+/* One reflected Euler-Maruyama update given the score (RD/sampling.py:198-207 with
+ * RSDE.sde, RD/sde_lib.py:93-101): x_mean = x + g(t)^2*score/N, x' = x_mean + g(t)*sqrt(1/N)*z,
+ * both reflected.  t: device [B]; x_mean_out may be NULL. */
+int rdmi_em_update(const float* x, const float* score, const float* z, const float* t, float* x_out,
+                   float* x_mean_out, int B, int elems_per_sample, int N, double sigma_min, double sigma_max,
+                   void* stream);
+
+/* One reflected Langevin corrector step given the score (RD/sampling.py:222-231); the step
+ * size uses the means over THIS batch of ||score_b|| and ||z_b||.  scratch: device [2*B+2]. */
+int rdmi_langevin_update(const float* x, const float* score, const float* z, float* x_out, float* x_mean_out,
+                         float* scratch, int B, int elems_per_sample, float snr, void* stream);
+
+/* Sampler options (config.sampling.* and config.sde.*, RD/sampling.py:102-124, RD/run_vis.py:32-36). */
+typedef struct rdmi_pc_opts {
+    int N;                 /* sde.N (num_scales): N-1 updates are applied          */
+    float eps;             /* last time of linspace(T=1, eps, N)                                */
+    double sigma_min, sigma_max; /* python floats in the reference (sde_lib.py:122-123): kept in double */
+    float snr;             /* config.sampling.snr                                               */
+    int n_steps_each;      /* corrector inner steps                                             */
+    int corrector;         /* 0 = none, 1 = langevin                                            */
+    int use_cfg;           /* 1: class_labels given -> get_cf_score_fn (2B forward); 0: get_score_fn */
+    uint64_t seed;         /* Philox seed for in-kernel N(0,1) noise when noise == NULL         */
+    uint64_t seq_offset;   /* Philox stream offset (e.g. rank * B) so shards draw disjoint noise */
+} rdmi_pc_opts;
+
+/* The whole PC sampling loop on the device: x (in: the prior draw, out: the sample) is updated
+ * N-1 times by [corrector x n_steps_each, predictor].  noise: NULL (Philox in-kernel) or device
+ * [(N-1)*(n_steps_each*corrector+1), B, H*W] tensors in consumption order (parity testing).
+ * trace: NULL or device [N-1, B, H*W] receiving x after every predictor update.
+ * teacher: NULL or device [N-1, B, H*W]: update i+1 restarts from teacher[i] (parity testing).
+ * Replaces: pc_sampler's hot loop (RD/sampling.py:322-337). */
+int rdmi_pc_sample(rdmi_ctx* ctx, float* x, const float* labels, const float* weight, const float* noise,
+                   float* trace, const float* teacher, int B, const rdmi_pc_opts* opts, unsigned flags,
+                   void* stream);
+
+/* Copy an internal activation (by reference module name, e.g. "down_blocks.0", "temb") of the LAST
+ * forward to dst as [B, C, H, W]; returns its C,H,W.  Debug / parity-test hook. */
+int rdmi_get_tap(rdmi_ctx* ctx, const char* name, float* dst, size_t dst_numel, int* C, int* H, int* W,
+                 void* stream);
+
+/* Per-kernel timing of the last rdmi_forward/rdmi_pc_sample when enabled (HIP events on `stream`). */
+int rdmi_set_profiling(rdmi_ctx* ctx, int enabled);
+int rdmi_get_profile(rdmi_ctx* ctx, int index, const char** kernel_name, double* total_ms, long* launches,
+                     double* flops_per_launch);
+
+const char* rdmi_last_error(void);
+const char* rdmi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDMI_H */

@@ -1,0 +1,28 @@
+// Shared device-side definitions for the gfx950 kernels of librdmi.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((vector_size(16)));
+
+// The single dynamic-LDS symbol (all kernels carve it themselves; base is 16-B aligned).
+extern __shared__ __attribute__((aligned(16))) unsigned char rdmi_lds[];
+
+#define RDMI_THREADS 256
+
+__device__ __forceinline__ float silu_f(float y) { return __fdividef(y, 1.0f + __expf(-y)); }
+
+// v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain), 1024 MAC per wave-instruction.
+// lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15];
+// result: col = l&15, rows (l>>4)*4 + r in element r.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// cube.reflect (RD/cube.py:34-49): floor-mod 2 then fold (1,2] onto [0,1).
+// x - 2*floor(x/2) is exact for the even multiple and rounds once, like torch.remainder.
+__device__ __forceinline__ float reflect_f(float x) {
+    float m = x - 2.0f * floorf(x * 0.5f);
+    // guard the fp32 edge where a tiny negative x rounds m to exactly 2.0
+    m = (m >= 2.0f) ? 0.0f : m;
+    return (m > 1.0f) ? 2.0f - m : m;
+}

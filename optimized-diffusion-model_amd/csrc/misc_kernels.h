@@ -1,0 +1,319 @@
+// Small kernels around the conv/attention core: weight repacking, the time/label embedding GEMMs,
+// the sampler's elementwise updates (CFG combine, reflected Euler-Maruyama, reflected Langevin),
+// Philox noise and layout copies.
+#pragma once
+#include "common.h"
+
+// --------------------------------------------------------------------------------------------
+// Weight repack: reference layouts -> [tap][K/16][Npad][16] (K = input channel, N = output channel).
+// One launch for every parameter: blockIdx.y = job.
+// --------------------------------------------------------------------------------------------
+struct PackJob {
+    const float* src;
+    float* dst;
+    int Cin, Cout;            // real dims of the source
+    int Kpad;                 // padded input channels (multiple of 16)
+    int Npad;                 // padded output channels OF THE DESTINATION (may hold several jobs side by side)
+    int n_off;                // first destination column of this job
+    int ntap;
+    long s_co, s_ci, s_t;     // source strides (elements) of output channel, input channel, tap
+    int kind;                 // 0: pack weights, 1: plain copy of Cout floats to dst + n_off
+};
+
+__global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    const int stride = gridDim.x * RDMI_THREADS;
+    if (j.kind == 1) {
+        for (int i = blockIdx.x * RDMI_THREADS + threadIdx.x; i < j.Cout; i += stride) j.dst[j.n_off + i] = j.src[i];
+        return;
+    }
+    // destination element (t, ch, co_local, kk): each job owns the columns [n_off, n_off + ceil16(Cout))
+    const int ncol = (j.Cout + 15) & ~15;
+    const long total = (long)j.ntap * (j.Kpad >> 4) * ncol * 16;
+    for (long i = blockIdx.x * RDMI_THREADS + threadIdx.x; i < total; i += stride) {
+        const int kk = (int)(i & 15);
+        long r = i >> 4;
+        const int co = (int)(r % ncol); r /= ncol;
+        const int ch = (int)(r % (j.Kpad >> 4));
+        const int t = (int)(r / (j.Kpad >> 4));
+        const int ci = ch * 16 + kk;
+        float v = 0.f;
+        if (co < j.Cout && ci < j.Cin) v = j.src[co * j.s_co + ci * j.s_ci + t * j.s_t];
+        j.dst[(((long)t * (j.Kpad >> 4) + ch) * j.Npad + j.n_off + co) * 16 + kk] = v;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Y[M][N] = pre(X)[M][K] . W + bias (+ label embedding), W packed [K/16][Npad][16]; MFMA 16x16x4.
+//   pre = 0: X as is; 1: SiLU(X); 2: Gaussian Fourier features of log(sigma)  (RD/models/layerspp.py:26-28)
+// Used for time_mlp.0, time_mlp.2 (+label_emb) and the 17 concatenated Dense_0 projections
+// (RD/models/ncsnpp.py:252-262, RD/models/layerspp.py:202).
+// grid = (ceil(M/16), Npad/64): a workgroup is one 16-row tile x 64 columns, one column tile per wave.
+// --------------------------------------------------------------------------------------------
+struct LinArgs {
+    const float* X; int ldx;
+    const float* W; int Npad;
+    const float* bias;
+    float* Y; int ldy;
+    int M, N, K;
+    int pre;
+    // pre == 2: X = sigma (or sde-time t when t_is_time) of sample (row % x_mod)
+    const float* fourW; int nfour; int x_mod; int t_is_time; float smin, ratio;
+    // optional label embedding added in the epilogue: labels [label_rows][ncls] (rows beyond are zero labels)
+    const float* labels; const float* Wl; const float* bl; int ncls; int label_rows;
+};
+
+__device__ __forceinline__ float sigma_of(float v, int t_is_time, float smin, float ratio) {
+    // RVESDE.marginal_prob std (RD/sde_lib.py:143): sigma_min * (sigma_max/sigma_min) ** t
+    // (ratio = fp32(sigma_max/sigma_min) is formed on the host in double, like the python float it is)
+    return t_is_time ? smin * powf(ratio, v) : v;
+}
+
+__global__ __launch_bounds__(RDMI_THREADS) void linear_mfma_kernel(LinArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int row = blockIdx.x * 16 + lrow;
+    const int col = blockIdx.y * 64 + wave * 16 + lrow;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float ls = 0.f;
+    if (a.pre == 2 && row < a.M) ls = logf(sigma_of(a.X[row % a.x_mod], a.t_is_time, a.smin, a.ratio));
+    for (int ch = 0; ch < (a.K >> 4); ++ch) {
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(a.W + ((size_t)ch * a.Npad + col) * 16 + kq * 4);
+        f32x4 af = {0.f, 0.f, 0.f, 0.f};
+        if (row < a.M) {
+            const int k0 = ch * 16 + kq * 4;
+            if (a.pre == 2) {
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + j;
+                    // x[:, None] * W[None, :] * 2 * np.pi, evaluated left to right in fp32
+                    const float arg = ((ls * a.fourW[k % a.nfour]) * 2.0f) * 3.14159265358979323846f;
+                    af[j] = k < a.nfour ? sinf(arg) : cosf(arg);
+                }
+            } else {
+                af = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + k0);
+                if (a.pre == 1)
+                    for (int j = 0; j < 4; ++j) af[j] = silu_f(af[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma16(af[j], bf[j], acc);
+    }
+    if (col < a.N) {
+        float add = a.bias ? a.bias[col] : 0.f;
+        if (a.labels) add += a.bl[col];
+        for (int r = 0; r < 4; ++r) {
+            const int orow = blockIdx.x * 16 + kq * 4 + r;
+            if (orow >= a.M) continue;
+            float v = acc[r] + add;
+            if (a.labels && orow < a.label_rows)
+                for (int c = 0; c < a.ncls; ++c) v += a.labels[(size_t)orow * a.ncls + c] * a.Wl[(size_t)col * a.ncls + c];
+            a.Y[(size_t)orow * a.ldy + col] = v;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator -> N(0,1) by Box-Muller.  counter = (element/4, draw index, stream),
+// key = seed: any (draw, element) can be generated independently -> no RNG state, graph-replay safe.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t quad, uint32_t draw) {
+    uint32_t c[4] = {(uint32_t)quad, (uint32_t)(quad >> 32), draw, 0x52444d49u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float s = 2.3283064365386963e-10f;   // 2^-32
+    const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
+    const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    const float t0 = 6.283185307179586f * u1, t1 = 6.283185307179586f * u3;
+    return f32x4{r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1)};
+}
+
+// z[i] for element i of draw `draw`; elements are numbered seq_offset*E + b*E + e so shards are disjoint
+__global__ __launch_bounds__(RDMI_THREADS) void philox_normal_kernel(float* __restrict__ z, long n, uint64_t seed,
+                                                                      uint64_t elem_offset, const int* draw_ctr,
+                                                                      int draw_add) {
+    const uint32_t draw = (uint32_t)((draw_ctr ? *draw_ctr : 0) + draw_add);
+    const long q = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (q * 4 >= n) return;
+    // quads are aligned to the GLOBAL element index so a shard draws exactly what the full batch would
+    const uint64_t g0 = elem_offset + (uint64_t)q * 4;
+    const f32x4 a = philox_normal4(seed, g0 >> 2, draw);
+    if ((g0 & 3) == 0) {
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) z[q * 4 + j] = a[j];
+    } else {
+        const f32x4 b = philox_normal4(seed, (g0 >> 2) + 1, draw);
+        const int sh = (int)(g0 & 3);
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) z[q * 4 + j] = (sh + j < 4) ? a[sh + j] : b[sh + j - 4];
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Sampler elementwise kernels
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RDMI_THREADS) void reflect_kernel(const float* __restrict__ in, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i < n) out[i] = reflect_f(in[i]);
+}
+
+// score = (1 + w) * s[0:B] - w * s[B:2B]      (RD/models/utils.py:124-138)
+__global__ __launch_bounds__(RDMI_THREADS) void cfg_combine_kernel(const float* __restrict__ s2, const float* __restrict__ w,
+                                                                    float* __restrict__ out, int B, int E) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)B * E) return;
+    const float wt = w ? w[i / E] : 0.f;
+    out[i] = (1.0f + wt) * s2[i] - wt * s2[(long)B * E + i];
+}
+
+struct StepState {            // device-resident loop state so one captured step graph can be replayed
+    int step;                 // index i of the current update (timesteps[i])
+    int draw;                 // number of noise tensors consumed so far
+};
+
+// Reflected Euler-Maruyama update (RD/sampling.py:198-207, RD/sde_lib.py:93-101,135-140).
+// t_vec: per-sample times, or (t_vec == null) the scalar ts[state->step] for every sample.
+// z: noise tensor for this update: zbase + draw * B * E when zstride_by_draw, else zbase.
+__global__ __launch_bounds__(RDMI_THREADS) void em_update_kernel(
+    const float* __restrict__ x, const float* __restrict__ score, const float* __restrict__ zbase,
+    const float* __restrict__ t_vec, const float* __restrict__ ts, const StepState* __restrict__ st,
+    float* __restrict__ x_out, float* __restrict__ x_mean_out, float* __restrict__ trace,
+    int B, int E, int N, float smin, float ratio, float gconst, int z_by_draw) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)B * E) return;
+    const float t = t_vec ? t_vec[i / E] : ts[st->step];
+    const float sigma = smin * powf(ratio, t);
+    const float g = sigma * gconst;                       // diffusion, RD/sde_lib.py:138-139
+    const float dt = -1.0f / (float)N;
+    const float* z = z_by_draw ? zbase + (long)st->draw * B * E : zbase;
+    const float drift = 0.0f - (g * g) * score[i];        // RSDE.sde, RD/sde_lib.py:97-98
+    const float xm = x[i] + drift * dt;
+    const float xn = xm + (g * sqrtf(-dt)) * z[i];
+    const float xr = reflect_f(xn);
+    x_out[i] = xr;
+    if (x_mean_out) x_mean_out[i] = reflect_f(xm);
+    if (trace) trace[(long)st->step * B * E + i] = xr;
+}
+
+// Langevin corrector, part 1: per-sample L2 norms of score and noise (RD/sampling.py:225-226).
+__global__ __launch_bounds__(64) void row_norms_kernel(const float* __restrict__ score, const float* __restrict__ zbase,
+                                                      const StepState* __restrict__ st, float* __restrict__ norms,
+                                                      int B, int E, int z_by_draw) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* z = z_by_draw ? zbase + (long)st->draw * B * E : zbase;
+    float s2 = 0.f, z2 = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const float sv = score[(long)b * E + e], zv = z[(long)b * E + e];
+        s2 += sv * sv; z2 += zv * zv;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { s2 += __shfl_xor(s2, m); z2 += __shfl_xor(z2, m); }
+    if (lane == 0) { norms[b] = sqrtf(s2); norms[B + b] = sqrtf(z2); }
+}
+
+// part 2: step = 2*(snr*mean||z||/mean||s||)^2 (one scalar for the batch); x_mean = x + step*s;
+// x' = x_mean + sqrt(2*step)*z; reflect both (RD/sampling.py:227-231).  Every workgroup re-reduces the
+// 2B norms in a fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(RDMI_THREADS) void langevin_update_kernel(
+    const float* __restrict__ x, const float* __restrict__ score, const float* __restrict__ zbase,
+    const float* __restrict__ norms, const StepState* __restrict__ st, float* __restrict__ x_out,
+    float* __restrict__ x_mean_out, int B, int E, float snr, int z_by_draw) {
+    float* red = reinterpret_cast<float*>(rdmi_lds);     // [2][4]
+    const int tid = threadIdx.x;
+    float gs = 0.f, zs = 0.f;
+    for (int b = tid; b < B; b += RDMI_THREADS) { gs += norms[b]; zs += norms[B + b]; }
+    for (int m = 32; m >= 1; m >>= 1) { gs += __shfl_xor(gs, m); zs += __shfl_xor(zs, m); }
+    if ((tid & 63) == 0) { red[tid >> 6] = gs; red[4 + (tid >> 6)] = zs; }
+    __syncthreads();
+    const float gmean = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+    const float zmean = (red[4] + red[5] + red[6] + red[7]) / (float)B;
+    const float r = snr * zmean / gmean;
+    const float step = r * r * 2.0f;
+    const float nscale = sqrtf(step * 2.0f);
+    const float* z = z_by_draw ? zbase + (long)st->draw * B * E : zbase;
+    const long i = (long)blockIdx.x * RDMI_THREADS + tid;
+    if (i < (long)B * E) {
+        const float xm = x[i] + step * score[i];
+        x_out[i] = reflect_f(xm + nscale * z[i]);
+        if (x_mean_out) x_mean_out[i] = reflect_f(xm);
+    }
+}
+
+// parity testing: restart the next update from the recorded state of the reference trajectory
+__global__ __launch_bounds__(RDMI_THREADS) void teacher_copy_kernel(float* __restrict__ x, const float* __restrict__ teacher,
+                                                                     const StepState* __restrict__ st, long BE) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i < BE) x[i] = teacher[(long)st->step * BE + i];
+}
+
+// advance the device-resident loop state (single work-item; stream order makes it race-free)
+__global__ void step_advance_kernel(StepState* st, int dstep, int ddraw) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->step += dstep; st->draw += ddraw; }
+}
+
+// fill a [M] vector with ts[step] (all samples share one time per update, RD/sampling.py:329)
+__global__ void fill_time_kernel(float* dst, const float* ts, const StepState* st, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) dst[i] = ts[st->step];
+}
+
+// cube.score_hk (RD/cube.py:73-193): score of the reflected heat kernel with t = sigma^2/2 per sample.
+//   t > cutoff : eigenfunction series  -2pi sum_k k e^{-t k^2 pi^2} sin(k pi x) cos(k pi x0)
+//                                      / (1 + 2 sum_k e^{-t k^2 pi^2} cos(k pi x) cos(k pi x0) + 1e-12)
+//   otherwise  : images x_r in {2j + x, 2j - x}, j = -refls..refls:
+//                sum sign (-2 (x_r - x0) / 4t) e^{-(x_r - x0)^2 / 4t} / (sum e^{...} + 1e-12)
+__global__ __launch_bounds__(RDMI_THREADS) void score_hk_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                                                 const float* __restrict__ sigma, float* __restrict__ out,
+                                                                 int B, int E, int efs, int refls, float cutoff) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)B * E) return;
+    const float sg = sigma[i / E];
+    const float t = sg * sg / 2.0f;
+    const float xv = x[i], ov = x0[i];
+    const float pi = 3.14159265358979323846f;
+    float num = 0.f, den = 0.f;
+    if (t > cutoff) {
+        const float pi2 = (float)(3.14159265358979323846 * 3.14159265358979323846);
+        for (int k = 1; k <= efs; ++k) {
+            const float kf = (float)k;
+            const float xr = (pi * xv) * kf, orr = (pi * ov) * kf;
+            const float ed = expf((-t * (kf * kf)) * pi2);
+            const float co = cosf(orr);
+            num += (ed * kf) * (sinf(xr) * co);
+            den += ed * (cosf(xr) * co);
+        }
+        out[i] = ((float)(-2.0 * 3.14159265358979323846) * num) / ((1.0f + 2.0f * den) + 1e-12f);
+    } else {
+        const float fourt = 4.0f * t;
+        for (int half = 0; half < 2; ++half)
+            for (int j = -refls; j <= refls; ++j) {
+                const float r = (float)(2 * j);
+                const float xm = (half == 0 ? r + xv : r - xv) - ov;
+                const float e = expf(-(xm * xm) / fourt);
+                const float cf = -2.0f * xm / fourt;
+                num += (cf * e) * (half == 0 ? 1.0f : -1.0f);
+                den += e;
+            }
+        out[i] = num / (den + 1e-12f);
+    }
+}
+
+// NHWC -> NCHW copy (debug taps and the C=1 boundary is a no-op)
+__global__ __launch_bounds__(RDMI_THREADS) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                     int NB, int HW, int C) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)NB * HW * C) return;
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int p = (int)(r % HW);
+    const long n = r / HW;
+    dst[(n * C + c) * HW + p] = src[i];
+}

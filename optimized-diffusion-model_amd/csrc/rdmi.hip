@@ -1,0 +1,1052 @@
+// librdmi: host side of the MI355X-native NCSN++ / reflected PC sampler (C ABI in include/rdmi.h).
+//
+// Structure: rdmi_create() turns the architecture keys into a static LAUNCH PLAN -- a list of fused
+// kernels over a liveness-packed NHWC activation workspace -- mirroring the data flow of
+// NCSNpp.forward (RD/models/ncsnpp.py:226-354).  Entry points replay the plan on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rdmi.h"
+#include "attn_kernel.h"
+#include "conv_kernel.h"
+#include "misc_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int pad16(int a) { return (a + 15) & ~15; }
+
+struct Param {
+    std::string name;
+    std::vector<int> shape;
+    size_t numel = 0;
+    const float* ptr = nullptr;
+};
+
+struct Tensor {
+    std::string name;
+    int C = 0, H = 0, W = 0;
+    size_t off = 0;           // floats per sample from the workspace base (times max_batch)
+    int def = -1, last = -1;  // defining / last-reading op index
+    size_t per_sample() const { return (size_t)C * H * W; }
+};
+
+enum OpKind { OP_CONV, OP_ATTN };
+
+struct Op {
+    OpKind kind;
+    std::string name;
+    ConvArgs conv{};
+    AttnArgs attn{};
+    int cfg = 0;                 // conv tile configuration
+    int out_tensor = -1;
+    double flops_per_sample = 0;
+    // tensor ids, resolved to pointers once the workspace is allocated
+    int tA = -1, tB = -1, tScA = -1, tScB = -1, tRes = -1;
+    bool a_is_input = false;     // A source is the caller's x (input_conv)
+    bool out_is_output = false;  // writes the caller's out (out_conv)
+    bool use_dense = false;      // epilogue adds this block's Dense_0(SiLU(temb)) column slice
+    std::vector<int> tab, mapA, mapSc;
+    size_t tab_off = 0, mapA_off = 0, mapSc_off = 0;   // into the int arena
+    bool has_mapA = false, has_mapSc = false;
+    // packed weight locations (floats into the weight arena)
+    size_t w_off = 0, wsc_off = 0, w3_off = 0, bqkv_off = 0;
+    std::string p_gamma, p_beta, p_bias, p_bias_sc, p_b3;
+};
+
+struct ProfEntry { std::string name; double ms = 0; long launches = 0; double flops = 0; };
+
+}  // namespace
+
+struct rdmi_ctx {
+    rdmi_arch arch{};
+    int max_batch = 0, H = 0, W = 0;
+    int temb = 0, dense_total = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::vector<PackJob> jobs;          // host copy (src pointers patched from params before upload)
+    std::vector<int> job_param;         // param index feeding each job
+    PackJob* d_jobs = nullptr;
+    float* d_w = nullptr;               // packed weight arena
+    size_t w_floats = 0;
+    int* d_int = nullptr;               // tables and pixel maps
+    float* ws = nullptr;                // activation workspace
+    size_t ws_per_sample = 0;
+    // embedding path
+    size_t w_t0 = 0, w_t2 = 0, w_dense = 0, b_dense = 0;
+    float *d_h1 = nullptr, *d_temb = nullptr, *d_dense = nullptr;
+    // sampler scratch
+    float *d_s2 = nullptr, *d_score = nullptr, *d_z = nullptr, *d_norms = nullptr, *d_ts = nullptr, *d_tvec = nullptr;
+    int ts_cap = 0;
+    StepState* d_state = nullptr;
+    bool packed_valid = false;
+    bool debug_taps = false;
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_entry;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// parameter list: the reference's state-dict order (RD/models/ncsnpp.py:42-224)
+// ------------------------------------------------------------------------------------------
+void add_param(rdmi_ctx* c, const std::string& name, std::vector<int> shape) {
+    Param p;
+    p.name = name;
+    p.shape = shape;
+    p.numel = 1;
+    for (int s : shape) p.numel *= (size_t)s;
+    c->pindex[name] = (int)c->params.size();
+    c->params.push_back(p);
+}
+void add_gn(rdmi_ctx* c, const std::string& pre, int ch) { add_param(c, pre + ".weight", {ch}); add_param(c, pre + ".bias", {ch}); }
+void add_conv_p(rdmi_ctx* c, const std::string& pre, int cin, int cout) { add_param(c, pre + ".weight", {cout, cin, 3, 3}); add_param(c, pre + ".bias", {cout}); }
+void add_nin(rdmi_ctx* c, const std::string& pre, int cin, int cout) { add_param(c, pre + ".W", {cin, cout}); add_param(c, pre + ".b", {cout}); }
+void add_resblock_p(rdmi_ctx* c, const std::string& pre, int cin, int cout) {
+    add_gn(c, pre + ".GroupNorm_0", cin);
+    add_conv_p(c, pre + ".Conv_0", cin, cout);
+    add_param(c, pre + ".Dense_0.weight", {cout, c->temb});
+    add_param(c, pre + ".Dense_0.bias", {cout});
+    add_gn(c, pre + ".GroupNorm_1", cout);
+    add_conv_p(c, pre + ".Conv_1", cout, cout);
+    if (cin != cout) add_nin(c, pre + ".NIN_0", cin, cout);
+}
+void add_attn_p(rdmi_ctx* c, const std::string& pre, int ch) {
+    add_gn(c, pre + ".GroupNorm_0", ch);
+    for (int i = 0; i < 4; ++i) add_nin(c, pre + ".NIN_" + std::to_string(i), ch, ch);
+}
+
+struct BlockSpec { std::string name; int cin, cout; bool attn; int level; };
+
+struct Layout {
+    std::vector<BlockSpec> down, up;       // in execution order
+    std::vector<int> skip_ch;
+    int mid_ch = 0;
+};
+
+Layout build_layout(rdmi_ctx* c) {
+    const rdmi_arch& a = c->arch;
+    Layout L;
+    int in_ch = a.nf, d = 0;
+    for (int i = 0; i < a.n_levels; ++i) {
+        const int out_ch = a.nf * a.ch_mult[i];
+        for (int j = 0; j < a.num_res_blocks; ++j) {
+            L.down.push_back({"down_blocks." + std::to_string(d), in_ch, out_ch, (a.attn_levels >> i & 1) != 0, i});
+            in_ch = out_ch;
+            L.skip_ch.push_back(in_ch);
+            ++d;
+        }
+        L.skip_ch.push_back(in_ch);
+    }
+    L.mid_ch = in_ch;
+    std::vector<int> sk(L.skip_ch.rbegin(), L.skip_ch.rend());
+    int u = 0, k = 0;
+    for (int i = a.n_levels - 1; i >= 0; --i) {
+        const int out_ch = a.nf * a.ch_mult[i];
+        for (int j = 0; j < a.num_res_blocks + 1; ++j) {
+            L.up.push_back({"up_blocks." + std::to_string(u), in_ch + sk[k++], out_ch, (a.attn_levels >> i & 1) != 0, i});
+            in_ch = out_ch;
+            ++u;
+        }
+    }
+    return L;
+}
+
+void build_params(rdmi_ctx* c, const Layout& L) {
+    const rdmi_arch& a = c->arch;
+    add_param(c, "time_embed.W", {a.nf});
+    add_param(c, "time_mlp.0.weight", {c->temb, 2 * a.nf});
+    add_param(c, "time_mlp.0.bias", {c->temb});
+    add_param(c, "time_mlp.2.weight", {c->temb, c->temb});
+    add_param(c, "time_mlp.2.bias", {c->temb});
+    if (a.conditional) {
+        add_param(c, "label_emb.weight", {c->temb, a.num_classes});
+        add_param(c, "label_emb.bias", {c->temb});
+    }
+    add_conv_p(c, "input_conv", a.channels, a.nf);
+    for (auto& b : L.down) add_resblock_p(c, b.name, b.cin, b.cout);
+    for (size_t i = 0; i < L.down.size(); ++i)
+        if (L.down[i].attn) add_attn_p(c, "down_attn." + std::to_string(i), L.down[i].cout);
+    {
+        int ch = a.nf;
+        for (int i = 0; i < a.n_levels; ++i) {
+            ch = a.nf * a.ch_mult[i];
+            if (i != a.n_levels - 1) add_conv_p(c, "downsample." + std::to_string(i) + ".Conv_0", ch, ch);
+        }
+    }
+    add_resblock_p(c, "mid_block1", L.mid_ch, L.mid_ch);
+    add_resblock_p(c, "mid_block2", L.mid_ch, L.mid_ch);
+    for (auto& b : L.up) add_resblock_p(c, b.name, b.cin, b.cout);
+    for (size_t i = 0; i < L.up.size(); ++i)
+        if (L.up[i].attn) add_attn_p(c, "up_attn." + std::to_string(i), L.up[i].cout);
+    for (int k = 0, i = a.n_levels - 1; i >= 1; --i, ++k) {
+        const int ch = a.nf * a.ch_mult[i];
+        add_conv_p(c, "upsample." + std::to_string(k) + ".Conv_0", ch, ch);
+    }
+    add_gn(c, "out_norm", a.nf * a.ch_mult[0]);
+    add_conv_p(c, "out_conv", a.nf * a.ch_mult[0], a.channels);
+}
+
+// ------------------------------------------------------------------------------------------
+// plan builder
+// ------------------------------------------------------------------------------------------
+struct Builder {
+    rdmi_ctx* c;
+    std::vector<int> ints;       // table / map arena (host)
+    size_t wf = 0;               // packed weight floats so far
+
+    int new_tensor(const std::string& name, int C, int H, int W) {
+        Tensor t;
+        t.name = name; t.C = C; t.H = H; t.W = W;
+        t.def = (int)c->ops.size();
+        c->tensors.push_back(t);
+        return (int)c->tensors.size() - 1;
+    }
+    void use(int t) { if (t >= 0) c->tensors[t].last = (int)c->ops.size(); }
+
+    size_t alloc_w(size_t n) { size_t o = wf; wf += (n + 63) & ~(size_t)63; return o; }
+
+    void job_pack(const std::string& pname, size_t dst_off, int Cin, int Cout, int Kpad, int Npad, int n_off, int ntap,
+                  long s_co, long s_ci, long s_t) {
+        PackJob j{};
+        j.dst = reinterpret_cast<float*>(dst_off);   // patched to a pointer after the arena exists
+        j.Cin = Cin; j.Cout = Cout; j.Kpad = Kpad; j.Npad = Npad; j.n_off = n_off; j.ntap = ntap;
+        j.s_co = s_co; j.s_ci = s_ci; j.s_t = s_t; j.kind = 0;
+        c->jobs.push_back(j);
+        c->job_param.push_back(c->pindex.at(pname));
+    }
+    void job_copy(const std::string& pname, size_t dst_off, int n, int n_off) {
+        PackJob j{};
+        j.dst = reinterpret_cast<float*>(dst_off);
+        j.Cout = n; j.n_off = n_off; j.kind = 1;
+        c->jobs.push_back(j);
+        c->job_param.push_back(c->pindex.at(pname));
+    }
+    // conv weight OIHW -> [9][Kpad/16][Npad][16]
+    size_t pack_conv(const std::string& pre, int cin, int cout) {
+        const int Kp = pad16(cin), Np = pad16(cout);
+        size_t o = alloc_w((size_t)9 * Kp * Np);
+        job_pack(pre + ".weight", o, cin, cout, Kp, Np, 0, 9, (long)cin * 9, 9, 1);
+        return o;
+    }
+    // NIN W [in][out] -> [Kpad/16][Npad][16]
+    size_t pack_nin(const std::string& pre, int cin, int cout) {
+        const int Kp = pad16(cin), Np = pad16(cout);
+        size_t o = alloc_w((size_t)Kp * Np);
+        job_pack(pre + ".W", o, cin, cout, Kp, Np, 0, 1, 1, cout, 0);
+        return o;
+    }
+
+    static std::vector<int> nearest_map(int Hs, int Ws, int Hd, int Wd) {
+        // F.interpolate(mode='nearest'): src = floor(dst * in / out)   (RD/models/ncsnpp.py:320, layerspp.py:122)
+        std::vector<int> m((size_t)Hd * Wd);
+        for (int y = 0; y < Hd; ++y)
+            for (int x = 0; x < Wd; ++x) {
+                int sy = std::min((int)std::floor(y * ((float)Hs / Hd)), Hs - 1);
+                int sx = std::min((int)std::floor(x * ((float)Ws / Wd)), Ws - 1);
+                m[(size_t)y * Wd + x] = sy * Ws + sx;
+            }
+        return m;
+    }
+
+    struct ConvSpec {
+        std::string name;
+        int tA = -1, tB = -1;           // sources (tA == -2: caller's x)
+        int CA = 0, CB = 0;
+        int Ha = 0, Wa = 0;             // source-A dims
+        int Hv = 0, Wv = 0;             // virtual input dims
+        std::string gn;                 // GroupNorm param prefix ("" = none)
+        std::string conv;               // conv param prefix
+        int stride = 1, pad_lo = 1;
+        int Ho = 0, Wo = 0, Cout = 0;
+        // shortcut
+        int tScA = -1, tScB = -1, CscA = 0, CscB = 0, Hsa = 0, Wsa = 0;
+        std::string nin;
+        int dense_off = -1;
+        int tRes = -1;
+        float scale = 1.f;
+        bool to_output = false;
+    };
+
+    int add_conv(const ConvSpec& s, int* err) {
+        Op op;
+        op.kind = OP_CONV;
+        op.name = s.name;
+        ConvArgs& a = op.conv;
+        const int Cin = s.CA + s.CB;
+        a.CA = s.CA; a.CB = s.CB; a.Cv = pad16(Cin);
+        a.HWa = s.Ha * s.Wa; a.HWv = s.Hv * s.Wv; a.HWo = s.Ho * s.Wo;
+        a.ntap = 9;
+        a.G = s.gn.empty() ? 0 : std::min(Cin / 4, 32);
+        a.Cout = s.Cout; a.Cout_pad = pad16(s.Cout);
+        a.out_scale = s.scale; a.eps = 1e-6f;
+        a.dense_stride = c->dense_total; a.dense_off = s.dense_off < 0 ? 0 : s.dense_off;
+        a.CscA = s.CscA; a.CscB = s.CscB; a.Csc = pad16(s.CscA + s.CscB) * ((s.CscA + s.CscB) > 0);
+        a.HWsa = s.Hsa * s.Wsa;
+        op.tA = s.tA; op.tB = s.tB; op.tScA = s.tScA; op.tScB = s.tScB; op.tRes = s.tRes;
+        op.a_is_input = (s.tA == -2);
+        op.out_is_output = s.to_output;
+        op.use_dense = s.dense_off >= 0;
+        // tile configuration
+        if (a.Cout_pad < 32) { op.cfg = 3; a.S = 1; a.BN = 16; }                   // <4,1,1,2,1>
+        else if (a.HWo >= 40) { op.cfg = 0; a.S = 1; a.BN = 64; }                  // <1,4,1,6,1>
+        else if (a.HWo >= 9) { op.cfg = 1; a.S = std::max(1, 64 / a.HWo); a.BN = 32; }   // <2,2,1,3,1>
+        else { op.cfg = 2; a.S = std::max(1, 16 / a.HWo); a.BN = 32; }             // <1,2,2,1,1>
+        if (const char* e = std::getenv("RDMI_CONV9_BN32")) if (atoi(e) && op.cfg == 0) { op.cfg = 1; a.BN = 32; }
+        a.Mpad = pad16(a.S * a.HWo);
+        const int cap[4] = {96, 96, 16, 128};
+        if (a.Mpad > cap[op.cfg] || a.Cout_pad % a.BN != 0) { *err = fail("conv %s: unsupported tile (HWo=%d Cout=%d)", s.name.c_str(), a.HWo, a.Cout); return -1; }
+        if (a.G > 0) {
+            const int pairs = a.S * a.G;
+            if (a.Cv != Cin || Cin % a.G != 0 || pairs > 256 || (pairs & (pairs - 1)) != 0) { *err = fail("conv %s: unsupported GroupNorm shape C=%d", s.name.c_str(), Cin); return -1; }
+        }
+        if (s.CA % 4 != 0 && s.CB != 0) { *err = fail("conv %s: unaligned concat", s.name.c_str()); return -1; }
+        if (conv_lds_bytes(a) > 160 * 1024) { *err = fail("conv %s: LDS tile %zu B too large", s.name.c_str(), conv_lds_bytes(a)); return -1; }
+        // tap table: row m = s*HWo + (oy*Wo + ox) -> LDS row s*HWv + iy*Wv + ix, or the zero row
+        const int zrow = a.S * a.HWv, zrow_sc = a.S * a.HWo;
+        op.tab.assign((size_t)a.Mpad * 10, zrow);
+        for (int m = 0; m < a.Mpad; ++m) {
+            const int sidx = m / a.HWo, p = m % a.HWo;
+            const bool real = m < a.S * a.HWo;
+            const int oy = p / s.Wo, ox = p % s.Wo;
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy * s.stride + t / 3 - s.pad_lo, ix = ox * s.stride + t % 3 - s.pad_lo;
+                if (real && iy >= 0 && iy < s.Hv && ix >= 0 && ix < s.Wv) op.tab[(size_t)m * 10 + t] = sidx * a.HWv + iy * s.Wv + ix;
+            }
+            op.tab[(size_t)m * 10 + 9] = real ? m : zrow_sc;
+        }
+        if (s.Ha != s.Hv || s.Wa != s.Wv) { op.mapA = nearest_map(s.Ha, s.Wa, s.Hv, s.Wv); op.has_mapA = true; }
+        if (a.Csc && (s.Hsa != s.Ho || s.Wsa != s.Wo)) { op.mapSc = nearest_map(s.Hsa, s.Wsa, s.Ho, s.Wo); op.has_mapSc = true; }
+        op.tab_off = ints.size(); ints.insert(ints.end(), op.tab.begin(), op.tab.end());
+        if (op.has_mapA) { op.mapA_off = ints.size(); ints.insert(ints.end(), op.mapA.begin(), op.mapA.end()); }
+        if (op.has_mapSc) { op.mapSc_off = ints.size(); ints.insert(ints.end(), op.mapSc.begin(), op.mapSc.end()); }
+        // weights
+        op.w_off = pack_conv(s.conv, Cin, s.Cout);
+        op.p_bias = s.conv + ".bias";
+        if (!s.gn.empty()) { op.p_gamma = s.gn + ".weight"; op.p_beta = s.gn + ".bias"; }
+        if (a.Csc) { op.wsc_off = pack_nin(s.nin, s.CscA + s.CscB, s.Cout); op.p_bias_sc = s.nin + ".b"; }
+        op.flops_per_sample = 2.0 * a.HWo * s.Cout * (9.0 * Cin + (s.CscA + s.CscB));
+        use(s.tA); use(s.tB); use(s.tScA); use(s.tScB); use(s.tRes);
+        int out = -1;
+        if (!s.to_output) { out = new_tensor(s.name, s.Cout, s.Ho, s.Wo); }
+        op.out_tensor = out;
+        c->ops.push_back(op);
+        return out;
+    }
+
+    int add_attn(const std::string& name, int tin, int C, int H, int W, int* err) {
+        Op op;
+        op.kind = OP_ATTN;
+        op.name = name;
+        if (C != 64 || H * W > 96) { *err = fail("attention %s: only C=64, H*W<=96 is built (got C=%d, L=%d)", name.c_str(), C, H * W); return -1; }
+        AttnArgs& a = op.attn;
+        a.L = H * W; a.Lpad = pad16(a.L); a.G = std::min(C / 4, 32);
+        a.eps = 1e-6f; a.scale = 1.0f / std::sqrt((float)C); a.out_scale = (float)(1.0 / std::sqrt(2.0));
+        op.tA = tin;
+        op.w_off = alloc_w((size_t)3 * C * C);
+        for (int i = 0; i < 3; ++i) {
+            PackJob j{};
+            j.dst = reinterpret_cast<float*>(op.w_off + (size_t)i * C * C);
+            j.Cin = C; j.Cout = C; j.Kpad = C; j.Npad = C; j.n_off = 0; j.ntap = 1; j.s_co = 1; j.s_ci = C; j.s_t = 0; j.kind = 0;
+            c->jobs.push_back(j);
+            c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
+        }
+        op.bqkv_off = alloc_w((size_t)3 * C);
+        for (int i = 0; i < 3; ++i) job_copy(name + ".NIN_" + std::to_string(i) + ".b", op.bqkv_off, C, i * C);
+        op.w3_off = pack_nin(name + ".NIN_3", C, C);
+        op.p_b3 = name + ".NIN_3.b";
+        op.p_gamma = name + ".GroupNorm_0.weight"; op.p_beta = name + ".GroupNorm_0.bias";
+        op.flops_per_sample = 2.0 * (4.0 * a.L * C * C + 2.0 * a.L * a.L * C);
+        use(tin);
+        const int out = new_tensor(name, C, H, W);
+        op.out_tensor = out;
+        c->ops.push_back(op);
+        return out;
+    }
+};
+
+// one ResnetBlockDDPMpp = two fused conv launches
+int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, int CB, int Ha, int Wa, int H, int W,
+                 int cout, int dense_off, int* err) {
+    Builder::ConvSpec s0;
+    s0.name = name + ".Conv_0";
+    s0.tA = tA; s0.tB = tB; s0.CA = CA; s0.CB = CB; s0.Ha = Ha; s0.Wa = Wa; s0.Hv = H; s0.Wv = W;
+    s0.gn = name + ".GroupNorm_0"; s0.conv = name + ".Conv_0";
+    s0.Ho = H; s0.Wo = W; s0.Cout = cout; s0.dense_off = dense_off;
+    const int h1 = b.add_conv(s0, err);
+    if (*err) return -1;
+    Builder::ConvSpec s1;
+    s1.name = name;
+    s1.tA = h1; s1.CA = cout; s1.Ha = H; s1.Wa = W; s1.Hv = H; s1.Wv = W;
+    s1.gn = name + ".GroupNorm_1"; s1.conv = name + ".Conv_1";
+    s1.Ho = H; s1.Wo = W; s1.Cout = cout;
+    s1.scale = (float)(1.0 / std::sqrt(2.0));
+    if (CA + CB != cout) {
+        s1.tScA = tA; s1.tScB = tB; s1.CscA = CA; s1.CscB = CB; s1.Hsa = Ha; s1.Wsa = Wa; s1.nin = name + ".NIN_0";
+    } else {
+        if (tB >= 0 || Ha != H || Wa != W) { *err = fail("%s: identity shortcut over a gathered input is not built", name.c_str()); return -1; }
+        s1.tRes = tA;
+    }
+    return b.add_conv(s1, err);
+}
+
+int build_plan(rdmi_ctx* c) {
+    const rdmi_arch& a = c->arch;
+    Layout L = build_layout(c);
+    build_params(c, L);
+    Builder b{c};
+    int err = 0;
+    // Dense_0 offsets in block order (down, mid1, mid2, up)
+    std::vector<std::pair<std::string, int>> dense_blocks;
+    for (auto& d : L.down) dense_blocks.push_back({d.name, d.cout});
+    dense_blocks.push_back({"mid_block1", L.mid_ch});
+    dense_blocks.push_back({"mid_block2", L.mid_ch});
+    for (auto& u : L.up) dense_blocks.push_back({u.name, u.cout});
+    std::map<std::string, int> dense_off;
+    int dt = 0;
+    for (auto& d : dense_blocks) { dense_off[d.first] = dt; dt += d.second; }
+    c->dense_total = dt;
+
+    // embedding weights: time_mlp.0 [temb][2nf], time_mlp.2 [temb][temb], all Dense_0 side by side
+    const int T = c->temb, Np_d = (dt + 63) & ~63, Np_t = (T + 63) & ~63;
+    c->w_t0 = b.alloc_w((size_t)pad16(2 * a.nf) * Np_t);
+    b.job_pack("time_mlp.0.weight", c->w_t0, 2 * a.nf, T, pad16(2 * a.nf), Np_t, 0, 1, 2 * a.nf, 1, 0);
+    c->w_t2 = b.alloc_w((size_t)T * Np_t);
+    b.job_pack("time_mlp.2.weight", c->w_t2, T, T, T, Np_t, 0, 1, T, 1, 0);
+    c->w_dense = b.alloc_w((size_t)T * Np_d);
+    c->b_dense = b.alloc_w((size_t)Np_d);
+    for (auto& d : dense_blocks) {
+        b.job_pack(d.first + ".Dense_0.weight", c->w_dense, T, d.second, T, Np_d, dense_off[d.first], 1, T, 1, 0);
+        b.job_copy(d.first + ".Dense_0.bias", c->b_dense, d.second, dense_off[d.first]);
+    }
+
+    // ---- NCSNpp.forward data flow
+    int H = c->H, W = c->W;
+    Builder::ConvSpec in;
+    in.name = "input_conv"; in.tA = -2; in.CA = a.channels; in.Ha = H; in.Wa = W; in.Hv = H; in.Wv = W;
+    in.conv = "input_conv"; in.Ho = H; in.Wo = W; in.Cout = a.nf;
+    int h = b.add_conv(in, &err);
+    if (err) return err;
+    struct HS { int t, C, H, W; };
+    std::vector<HS> hs{{h, a.nf, H, W}};
+    int ch = a.nf, d = 0;
+    for (int i = 0; i < a.n_levels; ++i) {
+        for (int j = 0; j < a.num_res_blocks; ++j, ++d) {
+            const BlockSpec& bs = L.down[d];
+            h = add_resblock(b, bs.name, h, -1, bs.cin, 0, H, W, H, W, bs.cout, dense_off[bs.name], &err);
+            if (err) return err;
+            ch = bs.cout;
+            if (bs.attn) { h = b.add_attn("down_attn." + std::to_string(d), h, ch, H, W, &err); if (err) return err; }
+            hs.push_back({h, ch, H, W});
+        }
+        hs.push_back({h, ch, H, W});
+        if (i != a.n_levels - 1) {
+            Builder::ConvSpec s;
+            s.name = "downsample." + std::to_string(i);
+            s.tA = h; s.CA = ch; s.Ha = H; s.Wa = W; s.Hv = H; s.Wv = W;
+            s.conv = s.name + ".Conv_0"; s.stride = 2; s.pad_lo = 0;
+            s.Ho = (H + 1 - 3) / 2 + 1; s.Wo = (W + 1 - 3) / 2 + 1; s.Cout = ch;
+            h = b.add_conv(s, &err);
+            if (err) return err;
+            H = s.Ho; W = s.Wo;
+        }
+    }
+    h = add_resblock(b, "mid_block1", h, -1, ch, 0, H, W, H, W, ch, dense_off["mid_block1"], &err);
+    if (err) return err;
+    h = add_resblock(b, "mid_block2", h, -1, ch, 0, H, W, H, W, ch, dense_off["mid_block2"], &err);
+    if (err) return err;
+    int u = 0;
+    for (int k = 0; k < a.n_levels; ++k) {
+        for (int j = 0; j < a.num_res_blocks + 1; ++j, ++u) {
+            const BlockSpec& bs = L.up[u];
+            HS sk = hs.back();
+            hs.pop_back();
+            // h is gathered (nearest) onto the skip's grid when the shapes differ (RD/models/ncsnpp.py:319-320)
+            const int Hs = H, Ws = W;
+            H = sk.H; W = sk.W;
+            h = add_resblock(b, bs.name, h, sk.t, ch, sk.C, Hs, Ws, H, W, bs.cout, dense_off[bs.name], &err);
+            if (err) return err;
+            ch = bs.cout;
+            if (bs.attn) { h = b.add_attn("up_attn." + std::to_string(u), h, ch, H, W, &err); if (err) return err; }
+        }
+        if (k != a.n_levels - 1) {
+            Builder::ConvSpec s;
+            s.name = "upsample." + std::to_string(k);
+            s.tA = h; s.CA = ch; s.Ha = H; s.Wa = W; s.Hv = 2 * H; s.Wv = 2 * W;
+            s.conv = s.name + ".Conv_0"; s.Ho = 2 * H; s.Wo = 2 * W; s.Cout = ch;
+            h = b.add_conv(s, &err);
+            if (err) return err;
+            H *= 2; W *= 2;
+        }
+    }
+    if (H != c->H || W != c->W) return fail("network output grid %dx%d != input %dx%d", H, W, c->H, c->W);
+    Builder::ConvSpec out;
+    out.name = "out_conv"; out.tA = h; out.CA = ch; out.Ha = H; out.Wa = W; out.Hv = H; out.Wv = W;
+    out.gn = "out_norm"; out.conv = "out_conv"; out.Ho = H; out.Wo = W; out.Cout = a.channels; out.to_output = true;
+    b.add_conv(out, &err);
+    if (err) return err;
+    if (a.channels != 1) return fail("channels=%d: the NHWC->NCHW output boundary is only built for channels=1", a.channels);
+
+    // ---- liveness-packed workspace offsets
+    {
+        struct Blk { size_t off, size; };
+        std::vector<Blk> freel;
+        std::vector<std::vector<int>> dies((size_t)c->ops.size() + 1);
+        for (size_t t = 0; t < c->tensors.size(); ++t) {
+            Tensor& tt = c->tensors[t];
+            if (tt.last < tt.def) tt.last = tt.def;
+            dies[(size_t)tt.last].push_back((int)t);
+        }
+        size_t top = 0;
+        size_t ti = 0;
+        for (size_t o = 0; o < c->ops.size(); ++o) {
+            // tensors defined by op o are allocated before tensors dying at o are released (an op never aliases in/out)
+            for (; ti < c->tensors.size() && c->tensors[ti].def == (int)o; ++ti) {
+                Tensor& tt = c->tensors[ti];
+                const size_t need = (tt.per_sample() + 63) & ~(size_t)63;
+                int best = -1;
+                if (!c->debug_taps)
+                    for (size_t f = 0; f < freel.size(); ++f)
+                        if (freel[f].size >= need && (best < 0 || freel[f].size < freel[(size_t)best].size)) best = (int)f;
+                if (best >= 0) {
+                    tt.off = freel[(size_t)best].off;
+                    if (freel[(size_t)best].size > need) { freel[(size_t)best].off += need; freel[(size_t)best].size -= need; }
+                    else freel.erase(freel.begin() + best);
+                } else { tt.off = top; top += need; }
+            }
+            for (int t : dies[o]) {
+                const Tensor& tt = c->tensors[(size_t)t];
+                freel.push_back({tt.off, (tt.per_sample() + 63) & ~(size_t)63});
+            }
+        }
+        c->ws_per_sample = top;
+    }
+
+    // ---- device allocations
+    c->w_floats = b.wf;
+    HIP_OK(hipMalloc((void**)&c->d_w, c->w_floats * sizeof(float)));
+    HIP_OK(hipMemset(c->d_w, 0, c->w_floats * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_int, std::max<size_t>(b.ints.size(), 1) * sizeof(int)));
+    HIP_OK(hipMemcpy(c->d_int, b.ints.data(), b.ints.size() * sizeof(int), hipMemcpyHostToDevice));
+    const size_t NBmax = (size_t)c->max_batch;
+    HIP_OK(hipMalloc((void**)&c->ws, c->ws_per_sample * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_jobs, c->jobs.size() * sizeof(PackJob)));
+    const size_t Mp = (size_t)pad16(c->max_batch);
+    HIP_OK(hipMalloc((void**)&c->d_h1, Mp * T * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_temb, Mp * T * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_dense, Mp * dt * sizeof(float)));
+    const size_t E = (size_t)c->H * c->W * a.channels;
+    HIP_OK(hipMalloc((void**)&c->d_s2, NBmax * E * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_score, NBmax * E * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_z, NBmax * E * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_norms, (2 * NBmax + 2) * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_tvec, NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_state, sizeof(StepState)));
+    HIP_OK(hipMemset(c->d_state, 0, sizeof(StepState)));
+    for (auto& j : c->jobs) j.dst = c->d_w + reinterpret_cast<size_t>(j.dst);
+
+    // ---- resolve pointers that do not depend on parameters
+    for (auto& op : c->ops) {
+        auto tptr = [&](int t) -> float* { return t >= 0 ? c->ws + c->tensors[(size_t)t].off * NBmax : nullptr; };
+        if (op.kind == OP_CONV) {
+            ConvArgs& ca = op.conv;
+            ca.srcA = tptr(op.tA); ca.srcB = tptr(op.tB); ca.scA = tptr(op.tScA); ca.scB = tptr(op.tScB);
+            ca.resid = tptr(op.tRes);
+            ca.out = tptr(op.out_tensor);
+            ca.tab = c->d_int + op.tab_off;
+            ca.mapA = op.has_mapA ? c->d_int + op.mapA_off : nullptr;
+            ca.mapSc = op.has_mapSc ? c->d_int + op.mapSc_off : nullptr;
+            ca.wpk = c->d_w + op.w_off;
+            ca.wsc = ca.Csc ? c->d_w + op.wsc_off : nullptr;
+            ca.dense = op.use_dense ? c->d_dense : nullptr;
+        } else {
+            AttnArgs& aa = op.attn;
+            aa.x = tptr(op.tA); aa.out = tptr(op.out_tensor);
+            aa.wqkv = c->d_w + op.w_off; aa.bqkv = c->d_w + op.bqkv_off; aa.w3 = c->d_w + op.w3_off;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------
+struct ProfScope {
+    rdmi_ctx* c; hipStream_t s; int entry = -1; size_t slot = 0;
+    ProfScope(rdmi_ctx* c_, hipStream_t s_, const std::string& name, double flops) : c(c_), s(s_) {
+        if (!c->profiling) return;
+        for (size_t i = 0; i < c->prof.size(); ++i) if (c->prof[i].name == name) entry = (int)i;
+        if (entry < 0) { c->prof.push_back({name, 0, 0, 0}); entry = (int)c->prof.size() - 1; }
+        c->prof[(size_t)entry].flops += flops;
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            c->ev_pool.push_back({a, b});
+            c->ev_entry.push_back(0);
+        }
+        slot = c->ev_used++;
+        c->ev_entry[slot] = entry;
+        hipEventRecord(c->ev_pool[slot].first, s);
+    }
+    ~ProfScope() { if (entry >= 0) hipEventRecord(c->ev_pool[slot].second, s); }
+};
+
+void prof_collect(rdmi_ctx* c) {
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        hipEventSynchronize(c->ev_pool[i].second);
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second);
+        ProfEntry& e = c->prof[(size_t)c->ev_entry[i]];
+        e.ms += ms; e.launches += 1;
+    }
+    c->ev_used = 0;
+}
+
+template <int WM, int WN, int WK, int MT, int NT>
+int launch_conv_t(const ConvArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = conv_mfma_kernel<WM, WN, WK, MT, NT>;
+    if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    dim3 grid((unsigned)ceil_div(a.NB, a.S), (unsigned)(a.Cout_pad / a.BN));
+    hipLaunchKernelGGL(k, grid, dim3(RDMI_THREADS), conv_lds_bytes(a), s, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int launch_conv(int cfg, const ConvArgs& a, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch_conv_t<1, 4, 1, 6, 1>(a, s);
+        case 1: return launch_conv_t<2, 2, 1, 3, 1>(a, s);
+        case 2: return launch_conv_t<1, 2, 2, 1, 1>(a, s);
+        case 3: return launch_conv_t<4, 1, 1, 2, 1>(a, s);
+    }
+    return fail("bad conv cfg %d", cfg);
+}
+
+const char* cfg_name(int cfg) {
+    static const char* n[] = {"conv_mfma<1,4,1,6,1>", "conv_mfma<2,2,1,3,1>", "conv_mfma<1,2,2,1,1>", "conv_mfma<4,1,1,2,1>"};
+    return n[cfg];
+}
+
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    auto k = attn_mfma_kernel<64>;
+    if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)a.NB), dim3(RDMI_THREADS), attn_lds_bytes<64>(a.Lpad, a.G), s, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+const float* P(rdmi_ctx* c, const std::string& name) { return c->params[(size_t)c->pindex.at(name)].ptr; }
+
+int do_repack(rdmi_ctx* c, hipStream_t s) {
+    for (size_t i = 0; i < c->jobs.size(); ++i) {
+        const Param& p = c->params[(size_t)c->job_param[i]];
+        if (!p.ptr) return fail("parameter '%s' was never bound (rdmi_set_param)", p.name.c_str());
+        c->jobs[i].src = p.ptr;
+    }
+    for (auto& p : c->params)
+        if (!p.ptr) return fail("parameter '%s' was never bound (rdmi_set_param)", p.name.c_str());
+    HIP_OK(hipMemcpyAsync(c->d_jobs, c->jobs.data(), c->jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(c, s, "pack_kernel", 0);
+        hipLaunchKernelGGL(pack_kernel, dim3(32, (unsigned)c->jobs.size()), dim3(RDMI_THREADS), 0, s, (const PackJob*)c->d_jobs);
+    }
+    HIP_OK(hipGetLastError());
+    // parameter-dependent pointers
+    for (auto& op : c->ops) {
+        if (op.kind == OP_CONV) {
+            ConvArgs& a = op.conv;
+            a.bias = P(c, op.p_bias);
+            a.bias_sc = op.p_bias_sc.empty() ? nullptr : P(c, op.p_bias_sc);
+            a.gamma = op.p_gamma.empty() ? nullptr : P(c, op.p_gamma);
+            a.beta = op.p_beta.empty() ? nullptr : P(c, op.p_beta);
+        } else {
+            op.attn.gamma = P(c, op.p_gamma); op.attn.beta = P(c, op.p_beta); op.attn.b3 = P(c, op.p_b3);
+        }
+    }
+    c->packed_valid = true;
+    return 0;
+}
+
+struct FwdIn {
+    const float* x; int x_mod;            // x holds x_mod samples; sample n reads x[n % x_mod] (0: n)
+    const float* sig; int sig_mod;        // sigma or t per sample (n % sig_mod); null with st: ts[st->step]
+    int t_is_time; float smin, ratio;
+    const float* labels; int label_rows;
+    float* out; int NB;
+};
+
+int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
+    const rdmi_arch& a = c->arch;
+    if (f.NB < 1 || f.NB > c->max_batch) return fail("batch %d outside [1, %d] (rdmi_create max_batch)", f.NB, c->max_batch);
+    if (a.conditional && !f.labels) return fail("class_labels is required: the model is conditional (label_emb) -- reference raises here too (RD/models/ncsnpp.py:262)");
+    const int T = c->temb, Np_t = (T + 63) & ~63, Np_d = (c->dense_total + 63) & ~63;
+    // ---- embedding: Fourier -> Linear -> SiLU -> Linear (+label_emb) -> [SiLU -> all Dense_0]
+    LinArgs l{};
+    l.M = f.NB; l.fourW = P(c, "time_embed.W"); l.nfour = a.nf;
+    l.X = f.sig; l.x_mod = f.sig_mod > 0 ? f.sig_mod : f.NB; l.t_is_time = f.t_is_time; l.smin = f.smin; l.ratio = f.ratio;
+    l.pre = 2; l.K = pad16(2 * a.nf); l.W = c->d_w + c->w_t0; l.Npad = Np_t; l.N = T; l.bias = P(c, "time_mlp.0.bias");
+    l.Y = c->d_h1; l.ldy = T;
+    {
+        ProfScope ps(c, s, "linear_mfma(time_mlp.0)", 2.0 * f.NB * T * 2 * a.nf);
+        hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l);
+    }
+    LinArgs l2{};
+    l2.M = f.NB; l2.X = c->d_h1; l2.ldx = T; l2.pre = 1; l2.K = T; l2.W = c->d_w + c->w_t2; l2.Npad = Np_t; l2.N = T;
+    l2.bias = P(c, "time_mlp.2.bias"); l2.Y = c->d_temb; l2.ldy = T;
+    if (a.conditional) { l2.labels = f.labels; l2.Wl = P(c, "label_emb.weight"); l2.bl = P(c, "label_emb.bias"); l2.ncls = a.num_classes; l2.label_rows = f.label_rows; }
+    {
+        ProfScope ps(c, s, "linear_mfma(time_mlp.2)", 2.0 * f.NB * T * T);
+        hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l2);
+    }
+    LinArgs l3{};
+    l3.M = f.NB; l3.X = c->d_temb; l3.ldx = T; l3.pre = 1; l3.K = T; l3.W = c->d_w + c->w_dense; l3.Npad = Np_d; l3.N = c->dense_total;
+    l3.bias = c->d_w + c->b_dense; l3.Y = c->d_dense; l3.ldy = c->dense_total;
+    {
+        ProfScope ps(c, s, "linear_mfma(Dense_0 x all)", 2.0 * f.NB * T * c->dense_total);
+        hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_d / 64)), dim3(RDMI_THREADS), 0, s, l3);
+    }
+    HIP_OK(hipGetLastError());
+    // ---- the U-Net
+    for (auto& op : c->ops) {
+        if (op.kind == OP_CONV) {
+            ConvArgs ca = op.conv;
+            ca.NB = f.NB;
+            if (op.a_is_input) { ca.srcA = f.x; ca.srcA_mod = f.x_mod; }
+            if (op.out_is_output) ca.out = f.out;
+            ProfScope ps(c, s, cfg_name(op.cfg), op.flops_per_sample * f.NB);
+            if (int e = launch_conv(op.cfg, ca, s)) return e;
+        } else {
+            AttnArgs aa = op.attn;
+            aa.NB = f.NB;
+            ProfScope ps(c, s, "attn_mfma<64>", op.flops_per_sample * f.NB);
+            if (int e = launch_attn(aa, s)) return e;
+        }
+    }
+    if (a.scale_by_sigma) return fail("scale_by_sigma=True is not built (all shipped NCSN++ configs set it False, RD/configs/model/ncsnpp.yaml)");
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+const char* rdmi_last_error(void) { return g_err.c_str(); }
+const char* rdmi_version(void) {
+#ifdef RDMI_EMU
+    return "rdmi 0.1 (CPU execution-model emulator build: tests only)";
+#else
+    return "rdmi 0.1 (gfx950)";
+#endif
+}
+
+int rdmi_create(const rdmi_arch* arch, int max_batch, int H, int W, rdmi_ctx** out) {
+    if (!arch || !out) return fail("null argument");
+    if (arch->n_levels < 1 || arch->n_levels > RDMI_MAX_LEVELS) return fail("n_levels=%d out of range", arch->n_levels);
+    if (arch->nf % 16 != 0) return fail("nf=%d must be a multiple of 16", arch->nf);
+    if (max_batch < 1 || H < 2 || W < 2) return fail("bad shape max_batch=%d H=%d W=%d", max_batch, H, W);
+    rdmi_ctx* c = new rdmi_ctx();
+    c->arch = *arch;
+    c->max_batch = max_batch; c->H = H; c->W = W;
+    c->temb = arch->nf * 4;
+    if (const char* e = std::getenv("RDMI_DEBUG_TAPS")) c->debug_taps = atoi(e) != 0;
+    int e = 0;
+    try { e = build_plan(c); } catch (const std::exception& ex) { e = fail("plan construction failed: %s", ex.what()); }
+    if (e) { rdmi_destroy(c); return e; }
+    *out = c;
+    return 0;
+}
+
+int rdmi_destroy(rdmi_ctx* c) {
+    if (!c) return 0;
+    void* ptrs[] = {c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    delete c;
+    return 0;
+}
+
+int rdmi_num_params(const rdmi_ctx* c) { return c ? (int)c->params.size() : 0; }
+
+int rdmi_param_info(const rdmi_ctx* c, int index, const char** name, size_t* numel) {
+    if (!c || index < 0 || index >= (int)c->params.size()) return fail("param index %d out of range", index);
+    if (name) *name = c->params[(size_t)index].name.c_str();
+    if (numel) *numel = c->params[(size_t)index].numel;
+    return 0;
+}
+
+int rdmi_set_param(rdmi_ctx* c, const char* name, const float* dev_ptr, size_t numel) {
+    if (!c || !name || !dev_ptr) return fail("null argument");
+    auto it = c->pindex.find(name);
+    if (it == c->pindex.end()) return fail("unknown parameter '%s'", name);
+    Param& p = c->params[(size_t)it->second];
+    if (p.numel != numel) return fail("parameter '%s': expected %zu elements, got %zu", name, p.numel, numel);
+    if (p.ptr != dev_ptr) c->packed_valid = false;
+    p.ptr = dev_ptr;
+    return 0;
+}
+
+int rdmi_repack(rdmi_ctx* c, void* stream) {
+    if (!c) return fail("null context");
+    return do_repack(c, (hipStream_t)stream);
+}
+
+static int maybe_repack(rdmi_ctx* c, unsigned flags, hipStream_t s) {
+    if ((flags & RDMI_PARAMS_CACHED) && c->packed_valid) return 0;
+    return do_repack(c, s);
+}
+
+int rdmi_forward(rdmi_ctx* c, const float* x, const float* sigma, const float* labels, float* out, int B,
+                 unsigned flags, void* stream) {
+    if (!c || !x || !sigma || !out) return fail("null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = maybe_repack(c, flags, s)) return e;
+    FwdIn f{x, 0, sigma, 0, 0, 0.f, 0.f, labels, B, out, B};
+    int e = run_forward(c, f, s);
+    if (c->profiling) prof_collect(c);
+    return e;
+}
+
+int rdmi_score(rdmi_ctx* c, const float* x, const float* t, const float* labels, float* out, int B,
+               double sigma_min, double sigma_max, unsigned flags, void* stream) {
+    if (!c || !x || !t || !out) return fail("null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = maybe_repack(c, flags, s)) return e;
+    FwdIn f{x, 0, t, 0, 1, (float)sigma_min, (float)(sigma_max / sigma_min), labels, B, out, B};
+    int e = run_forward(c, f, s);
+    if (c->profiling) prof_collect(c);
+    return e;
+}
+
+static int cf_score_impl(rdmi_ctx* c, const float* x, const float* t, int t_mod, const float* labels, const float* weight,
+                         float* out, int B, float smin, float ratio, hipStream_t s) {
+    const int E = c->H * c->W * c->arch.channels;
+    FwdIn f{x, B, t, t_mod, 1, smin, ratio, labels, B, c->d_s2, 2 * B};
+    if (int e = run_forward(c, f, s)) return e;
+    {
+        ProfScope ps(c, s, "cfg_combine", 0);
+        hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)ceil_div(B * E, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s,
+                           (const float*)c->d_s2, weight, out, B, E);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int rdmi_cf_score(rdmi_ctx* c, const float* x, const float* t, const float* labels, const float* weight, float* out,
+                  int B, double sigma_min, double sigma_max, unsigned flags, void* stream) {
+    if (!c || !x || !t || !labels || !out) return fail("null argument");
+    if (2 * B > c->max_batch) return fail("CFG needs a model batch of 2*B=%d > max_batch=%d", 2 * B, c->max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = maybe_repack(c, flags, s)) return e;
+    int e = cf_score_impl(c, x, t, B, labels, weight, out, B, (float)sigma_min, (float)(sigma_max / sigma_min), s);
+    if (c->profiling) prof_collect(c);
+    return e;
+}
+
+int rdmi_reflect(const float* in, float* out, size_t n, void* stream) {
+    if (!in || !out) return fail("null argument");
+    hipLaunchKernelGGL(reflect_kernel, dim3((unsigned)((n + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0,
+                       (hipStream_t)stream, in, out, (long)n);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int rdmi_score_hk(const float* x, const float* x_orig, const float* sigma, float* out, int B, int E, int efs, int refls,
+                  float min_cutoff, void* stream) {
+    if (!x || !x_orig || !sigma || !out) return fail("null argument");
+    hipLaunchKernelGGL(score_hk_kernel, dim3((unsigned)ceil_div(B * E, RDMI_THREADS)), dim3(RDMI_THREADS), 0, (hipStream_t)stream,
+                       x, x_orig, sigma, out, B, E, efs, refls, min_cutoff);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static float g_const(double smin, double smax) {
+    // torch.sqrt(torch.tensor(2 * (np.log(sigma_max) - np.log(sigma_min)), dtype=float32))   RD/sde_lib.py:138-139
+    return sqrtf((float)(2.0 * (std::log(smax) - std::log(smin))));
+}
+
+int rdmi_em_update(const float* x, const float* score, const float* z, const float* t, float* x_out, float* x_mean_out,
+                   int B, int E, int N, double sigma_min, double sigma_max, void* stream) {
+    if (!x || !score || !z || !t || !x_out) return fail("null argument");
+    hipLaunchKernelGGL(em_update_kernel, dim3((unsigned)ceil_div(B * E, RDMI_THREADS)), dim3(RDMI_THREADS), 0,
+                       (hipStream_t)stream, x, score, z, t, (const float*)nullptr, (const StepState*)nullptr, x_out,
+                       x_mean_out, (float*)nullptr, B, E, N, (float)sigma_min, (float)(sigma_max / sigma_min),
+                       g_const(sigma_min, sigma_max), 0);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int rdmi_langevin_update(const float* x, const float* score, const float* z, float* x_out, float* x_mean_out,
+                         float* scratch, int B, int E, float snr, void* stream) {
+    if (!x || !score || !z || !x_out || !scratch) return fail("null argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)B), dim3(64), 0, s, score, z, (const StepState*)nullptr, scratch, B, E, 0);
+    hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)ceil_div(B * E, RDMI_THREADS)), dim3(RDMI_THREADS), 64, s, x,
+                       score, z, (const float*)scratch, (const StepState*)nullptr, x_out, x_mean_out, B, E, snr, 0);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weight, const float* noise, float* trace,
+                   const float* teacher, int B, const rdmi_pc_opts* o, unsigned flags, void* stream) {
+    if (!c || !x || !o) return fail("null argument");
+    if (o->N < 2) return fail("N=%d: need at least 2 scales", o->N);
+    if (o->corrector != 0 && o->corrector != 1) return fail("unknown corrector id %d", o->corrector);
+    const int NBm = o->use_cfg ? 2 * B : B;
+    if (NBm > c->max_batch) return fail("model batch %d > max_batch=%d", NBm, c->max_batch);
+    if (o->use_cfg && !labels) return fail("use_cfg=1 needs class_labels");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = maybe_repack(c, flags, s)) return e;
+    const int E = c->H * c->W * c->arch.channels;
+    const long BE = (long)B * E;
+    // timesteps = torch.linspace(T=1, eps, N): fp32 step, fma(step, i, start) / fma(-step, N-1-i, end)
+    if (o->N > c->ts_cap) {
+        if (c->d_ts) hipFree(c->d_ts);
+        HIP_OK(hipMalloc((void**)&c->d_ts, (size_t)o->N * sizeof(float)));
+        c->ts_cap = o->N;
+    }
+    {
+        std::vector<float> ts((size_t)o->N);
+        const float start = 1.0f, end = o->eps;
+        const double step = (double)(float)((end - start) / (float)(o->N - 1));
+        for (int i = 0; i < o->N; ++i)
+            ts[(size_t)i] = (float)(i < o->N / 2 ? (double)start + step * i : (double)end - step * (o->N - 1 - i));
+        HIP_OK(hipMemcpyAsync(c->d_ts, ts.data(), ts.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));      // ts is a stack vector
+    }
+    HIP_OK(hipMemsetAsync(c->d_state, 0, sizeof(StepState), s));
+    const float smin = (float)o->sigma_min, ratio = (float)(o->sigma_max / o->sigma_min);
+    const float gc = g_const(o->sigma_min, o->sigma_max);
+    const unsigned gBE = (unsigned)ceil_div((int)BE, RDMI_THREADS);
+    const int z_by_draw = noise ? 1 : 0;
+    const float* zsrc = noise ? noise : c->d_z;
+
+    auto score_eval = [&]() -> int {
+        {
+            ProfScope tp(c, s, "fill_time", 0);
+            hipLaunchKernelGGL(fill_time_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, c->d_tvec, (const float*)c->d_ts,
+                               (const StepState*)c->d_state, B);
+        }
+        if (o->use_cfg) return cf_score_impl(c, x, c->d_tvec, B, labels, weight, c->d_score, B, smin, ratio, s);
+        FwdIn f{x, 0, c->d_tvec, 0, 1, smin, ratio, labels, B, c->d_score, B};
+        return run_forward(c, f, s);
+    };
+    auto draw_noise = [&](int draw_add) {
+        if (noise) return;
+        ProfScope ps(c, s, "philox_normal", 0);
+        hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)ceil_div((int)((BE + 3) / 4), RDMI_THREADS)), dim3(RDMI_THREADS), 0, s,
+                           c->d_z, BE, (uint64_t)o->seed, (uint64_t)o->seq_offset * (uint64_t)E, (const int*)&c->d_state->draw, draw_add);
+    };
+
+    for (int i = 0; i < o->N - 1; ++i) {
+        if (o->corrector == 1) {
+            for (int k = 0; k < o->n_steps_each; ++k) {
+                if (int e = score_eval()) return e;
+                draw_noise(0);
+                {
+                    ProfScope ps(c, s, "langevin_update", 0);
+                    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)c->d_score, zsrc,
+                                       (const StepState*)c->d_state, c->d_norms, B, E, z_by_draw);
+                    hipLaunchKernelGGL(langevin_update_kernel, dim3(gBE), dim3(RDMI_THREADS), 64, s, (const float*)x,
+                                       (const float*)c->d_score, zsrc, (const float*)c->d_norms, (const StepState*)c->d_state, x,
+                                       (float*)nullptr, B, E, o->snr, z_by_draw);
+                    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, c->d_state, 0, 1);
+                }
+            }
+        }
+        if (int e = score_eval()) return e;
+        draw_noise(0);
+        {
+            ProfScope ps(c, s, "em_update", 0);
+            hipLaunchKernelGGL(em_update_kernel, dim3(gBE), dim3(RDMI_THREADS), 0, s, (const float*)x, (const float*)c->d_score, zsrc,
+                               (const float*)nullptr, (const float*)c->d_ts, (const StepState*)c->d_state, x, (float*)nullptr, trace,
+                               B, E, o->N, smin, ratio, gc, z_by_draw);
+            if (teacher)
+                hipLaunchKernelGGL(teacher_copy_kernel, dim3(gBE), dim3(RDMI_THREADS), 0, s, x, teacher, (const StepState*)c->d_state, BE);
+            hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, c->d_state, 1, 1);
+        }
+        HIP_OK(hipGetLastError());
+        if (c->profiling && (i % 16 == 15)) prof_collect(c);
+    }
+    if (c->profiling) prof_collect(c);
+    return 0;
+}
+
+int rdmi_get_tap(rdmi_ctx* c, const char* name, float* dst, size_t dst_numel, int* C, int* H, int* W, void* stream) {
+    if (!c || !name || !dst) return fail("null argument");
+    if (!c->debug_taps) return fail("taps need RDMI_DEBUG_TAPS=1 at rdmi_create (buffers are reused otherwise)");
+    hipStream_t s = (hipStream_t)stream;
+    const std::string nm(name);
+    if (nm == "temb") {
+        if (C) *C = c->temb; if (H) *H = 1; if (W) *W = 1;
+        HIP_OK(hipMemcpyAsync(dst, c->d_temb, std::min(dst_numel, (size_t)c->max_batch * c->temb) * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    for (auto& t : c->tensors) {
+        if (t.name != nm) continue;
+        if (C) *C = t.C; if (H) *H = t.H; if (W) *W = t.W;
+        const size_t per = t.per_sample();
+        const int nb = (int)std::min<size_t>(dst_numel / per, (size_t)c->max_batch);
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)ceil_div((int)(nb * per), RDMI_THREADS)), dim3(RDMI_THREADS), 0, s,
+                           (const float*)(c->ws + t.off * (size_t)c->max_batch), dst, nb, t.H * t.W, t.C);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    return fail("no activation named '%s'", name);
+}
+
+int rdmi_set_profiling(rdmi_ctx* c, int enabled) {
+    if (!c) return fail("null context");
+    c->profiling = enabled != 0;
+    c->prof.clear();
+    c->ev_used = 0;
+    return 0;
+}
+
+int rdmi_get_profile(rdmi_ctx* c, int index, const char** kernel_name, double* total_ms, long* launches, double* flops) {
+    if (!c || index < 0 || index >= (int)c->prof.size()) return 1;
+    const ProfEntry& e = c->prof[(size_t)index];
+    if (kernel_name) *kernel_name = e.name.c_str();
+    if (total_ms) *total_ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (flops) *flops = e.flops;
+    return 0;
+}
+
+}  // extern "C"

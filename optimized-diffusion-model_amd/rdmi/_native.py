@@ -1,0 +1,243 @@
+"""ctypes binding of librdmi.so (C ABI: include/rdmi.h).
+
+There is exactly one compute backend: the HIP library built for gfx950.  If it is missing the
+import of anything that computes fails loudly -- there is no eager/torch/CPU fallback.
+(tests/ may point this module at the CPU *emulator build* of the very same sources with
+use_library(); the product never does.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT = os.path.join(_HERE, 'librdmi.so')
+_lib = None
+_lib_path = None
+
+RDMI_PARAMS_CACHED = 1
+RDMI_MAX_LEVELS = 8
+
+
+class Arch(C.Structure):
+    _fields_ = [('nf', C.c_int), ('n_levels', C.c_int), ('ch_mult', C.c_int * RDMI_MAX_LEVELS),
+                ('num_res_blocks', C.c_int), ('attn_levels', C.c_int), ('channels', C.c_int),
+                ('num_classes', C.c_int), ('conditional', C.c_int), ('scale_by_sigma', C.c_int),
+                ('fourier_2pi_prescaled', C.c_float)]
+
+
+class PcOpts(C.Structure):
+    _fields_ = [('N', C.c_int), ('eps', C.c_float), ('sigma_min', C.c_double), ('sigma_max', C.c_double),
+                ('snr', C.c_float), ('n_steps_each', C.c_int), ('corrector', C.c_int), ('use_cfg', C.c_int),
+                ('seed', C.c_uint64), ('seq_offset', C.c_uint64)]
+
+
+_F = C.c_void_p   # device float* travel as integers (tensor.data_ptr())
+_PROTOS = {
+    'rdmi_create': ([C.POINTER(Arch), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    'rdmi_destroy': ([C.c_void_p], C.c_int),
+    'rdmi_num_params': ([C.c_void_p], C.c_int),
+    'rdmi_param_info': ([C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)], C.c_int),
+    'rdmi_set_param': ([C.c_void_p, C.c_char_p, _F, C.c_size_t], C.c_int),
+    'rdmi_repack': ([C.c_void_p, C.c_void_p], C.c_int),
+    'rdmi_forward': ([C.c_void_p, _F, _F, _F, _F, C.c_int, C.c_uint, C.c_void_p], C.c_int),
+    'rdmi_score': ([C.c_void_p, _F, _F, _F, _F, C.c_int, C.c_double, C.c_double, C.c_uint, C.c_void_p], C.c_int),
+    'rdmi_cf_score': ([C.c_void_p, _F, _F, _F, _F, _F, C.c_int, C.c_double, C.c_double, C.c_uint, C.c_void_p], C.c_int),
+    'rdmi_reflect': ([_F, _F, C.c_size_t, C.c_void_p], C.c_int),
+    'rdmi_score_hk': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
+    'rdmi_em_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
+    'rdmi_langevin_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
+    'rdmi_pc_sample': ([C.c_void_p, _F, _F, _F, _F, _F, _F, C.c_int, C.POINTER(PcOpts), C.c_uint, C.c_void_p], C.c_int),
+    'rdmi_get_tap': ([C.c_void_p, C.c_char_p, _F, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                      C.POINTER(C.c_int), C.c_void_p], C.c_int),
+    'rdmi_set_profiling': ([C.c_void_p, C.c_int], C.c_int),
+    'rdmi_get_profile': ([C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long),
+                          C.POINTER(C.c_double)], C.c_int),
+    'rdmi_last_error': ([], C.c_char_p),
+    'rdmi_version': ([], C.c_char_p),
+}
+EXPORTS = tuple(_PROTOS)
+
+
+def use_library(path):
+    """Bind a specific build of the library (tests use this for the emulator build)."""
+    global _lib, _lib_path
+    lib = C.CDLL(path)
+    for name, (argt, rest) in _PROTOS.items():
+        fn = getattr(lib, name)       # AttributeError here = a symbol of include/rdmi.h is not exported
+        fn.argtypes, fn.restype = argt, rest
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def lib():
+    if _lib is None:
+        if not os.path.exists(_DEFAULT):
+            raise RuntimeError(
+                f'librdmi.so not found at {_DEFAULT}: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950).  rdmi has no fallback compute path.')
+        use_library(_DEFAULT)
+    return _lib
+
+
+def library_path():
+    lib()
+    return _lib_path
+
+
+def is_emulator():
+    return b'emulator' in lib().rdmi_version()
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('librdmi: ' + lib().rdmi_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a dense fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.is_contiguous(), 'librdmi takes dense fp32 tensors'
+    return t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+def require_device(t):
+    """The HIP build only accepts device memory; the emulator build (tests) only host memory."""
+    if is_emulator():
+        if t.is_cuda:
+            raise RuntimeError('emulator build of librdmi takes CPU tensors')
+    elif not t.is_cuda:
+        raise RuntimeError('librdmi (gfx950) takes tensors on a HIP device; got a CPU tensor and there is no CPU path')
+
+
+class Context:
+    """Owns one rdmi_ctx (workspace + launch plan) for a fixed (arch, H, W, max model batch, device)."""
+
+    def __init__(self, arch, max_batch, H, W, device):
+        self.device = torch.device(device)
+        self.max_batch, self.H, self.W = max_batch, H, W
+        self._h = C.c_void_p()
+        with self._guard():
+            check(lib().rdmi_create(C.byref(arch), max_batch, H, W, C.byref(self._h)))
+        self._bound = {}
+        n = lib().rdmi_num_params(self._h)
+        self.param_names = []
+        for i in range(n):
+            nm, ne = C.c_char_p(), C.c_size_t()
+            check(lib().rdmi_param_info(self._h, i, C.byref(nm), C.byref(ne)))
+            self.param_names.append((nm.value.decode(), ne.value))
+
+    def _guard(self):
+        return torch.cuda.device(self.device) if self.device.type == 'cuda' else _Null()
+
+    def bind(self, named_tensors):
+        """(Re)bind parameter storage; only pointers that changed are sent."""
+        for name, t in named_tensors:
+            p = t.data_ptr()
+            if self._bound.get(name) != p:
+                assert t.dtype == torch.float32 and t.is_contiguous()
+                check(lib().rdmi_set_param(self._h, name.encode(), p, t.numel()))
+                self._bound[name] = p
+
+    def close(self):
+        if self._h:
+            lib().rdmi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- entry points ---------------------------------------------------------------
+    def forward(self, x, sigma, labels, out, flags=0):
+        with self._guard():
+            check(lib().rdmi_forward(self._h, ptr(x), ptr(sigma), ptr(labels), ptr(out), x.shape[0], flags, stream_of(x)))
+
+    def score(self, x, t, labels, out, smin, smax, flags=0):
+        with self._guard():
+            check(lib().rdmi_score(self._h, ptr(x), ptr(t), ptr(labels), ptr(out), x.shape[0], smin, smax, flags, stream_of(x)))
+
+    def cf_score(self, x, t, labels, weight, out, smin, smax, flags=0):
+        with self._guard():
+            check(lib().rdmi_cf_score(self._h, ptr(x), ptr(t), ptr(labels), ptr(weight), ptr(out), x.shape[0], smin, smax,
+                                      flags, stream_of(x)))
+
+    def pc_sample(self, x, labels, weight, noise, trace, teacher, opts, flags=0):
+        with self._guard():
+            check(lib().rdmi_pc_sample(self._h, ptr(x), ptr(labels), ptr(weight), ptr(noise), ptr(trace), ptr(teacher),
+                                       x.shape[0], C.byref(opts), flags, stream_of(x)))
+
+    def get_tap(self, name, like, nb):
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        buf = torch.empty(self.max_batch * 256 * self.H * self.W * 4, dtype=torch.float32, device=like.device)
+        with self._guard():
+            check(lib().rdmi_get_tap(self._h, name.encode(), ptr(buf), buf.numel(), C.byref(c), C.byref(h), C.byref(w),
+                                     stream_of(like)))
+        n = c.value * h.value * w.value
+        return buf[:nb * n].reshape(nb, c.value, h.value, w.value).clone()
+
+    def set_profiling(self, on):
+        check(lib().rdmi_set_profiling(self._h, int(bool(on))))
+
+    def get_profile(self):
+        out, i = [], 0
+        while True:
+            nm, ms, n, fl = C.c_char_p(), C.c_double(), C.c_long(), C.c_double()
+            if lib().rdmi_get_profile(self._h, i, C.byref(nm), C.byref(ms), C.byref(n), C.byref(fl)) != 0:
+                break
+            out.append(dict(kernel=nm.value.decode(), ms=ms.value, launches=n.value, flops=fl.value))
+            i += 1
+        return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+# ---- stateless elementwise entry points ------------------------------------------------
+def reflect(x):
+    require_device(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib().rdmi_reflect(ptr(x), ptr(out), x.numel(), stream_of(x)))
+    return out
+
+
+def score_hk(x, x_orig, sigma, efs, refls, min_cutoff):
+    require_device(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    check(lib().rdmi_score_hk(ptr(x), ptr(x_orig.contiguous()), ptr(sigma.contiguous().float()), ptr(out), B, x.numel() // B,
+                              efs, refls, min_cutoff, stream_of(x)))
+    return out
+
+
+def em_update(x, score, z, t, N, smin, smax):
+    require_device(x)
+    x_out, x_mean = torch.empty_like(x), torch.empty_like(x)
+    B = x.shape[0]
+    check(lib().rdmi_em_update(ptr(x.contiguous()), ptr(score.contiguous()), ptr(z.contiguous()), ptr(t.contiguous()),
+                               ptr(x_out), ptr(x_mean), B, x.numel() // B, N, smin, smax, stream_of(x)))
+    return x_out, x_mean
+
+
+def langevin_update(x, score, z, snr):
+    require_device(x)
+    x_out, x_mean = torch.empty_like(x), torch.empty_like(x)
+    B = x.shape[0]
+    scratch = torch.empty(2 * B + 2, dtype=torch.float32, device=x.device)
+    check(lib().rdmi_langevin_update(ptr(x.contiguous()), ptr(score.contiguous()), ptr(z.contiguous()), ptr(x_out),
+                                     ptr(x_mean), ptr(scratch), B, x.numel() // B, snr, stream_of(x)))
+    return x_out, x_mean
