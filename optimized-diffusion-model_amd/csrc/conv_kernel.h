@@ -57,16 +57,20 @@ __host__ __device__ inline size_t conv_lds_bytes(const ConvArgs& a) {
     return f * 4;
 }
 
-// gather S samples of a [n][HWsrc][CA] (+ [n][HWdst][CB]) pair into LDS rows [s*HWdst + v][C + 4]
+// gather S samples of a [n][HWsrc][CA] (+ [n][HWdst][CB]) pair into LDS rows [s*HWdst + v][C + 4].
+// Work-item i handles float4 #i of the tile; (pixel, channel) are advanced incrementally (no divisions in the loop).
 __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const float* __restrict__ A,
                                            const float* __restrict__ B, const int* __restrict__ map, int CA,
                                            int CB, int Cpad, int HWsrc, int HWdst, int S, int n0, int NB,
                                            int a_mod, int tid) {
     const int c4n = Cpad >> 2;
     const int total = S * HWdst * c4n;
+    const int dpv = RDMI_THREADS / c4n, dc4 = RDMI_THREADS - dpv * c4n;
+    int pv = tid / c4n, c4 = tid - pv * c4n;
     for (int i = tid; i < total; i += RDMI_THREADS) {
-        const int pv = i / c4n, c = (i - pv * c4n) << 2;
-        const int s = pv / HWdst, v = pv - s * HWdst;
+        const int c = c4 << 2;
+        int s = 0, v = pv;
+        while (v >= HWdst) { v -= HWdst; ++s; }
         const int n = n0 + s;
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
         if (n < NB) {
@@ -84,15 +88,172 @@ __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const 
             }
         }
         *reinterpret_cast<f32x4*>(L + (size_t)pv * rs + c) = val;
+        pv += dpv; c4 += dc4;
+        if (c4 >= c4n) { c4 -= c4n; ++pv; }
     }
     for (int i = tid; i < rs; i += RDMI_THREADS) L[(size_t)S * HWdst * rs + i] = 0.f;   // the zero row
 }
 
-template <int WM, int WN, int WK, int MT, int NT>
+// The GEMM + epilogue for a wave that owns NMT row tiles (compile-time) x NT column tiles.
+// B fragments (weights) stream from L2 through a PF-deep register ring; A fragments come from LDS.
+template <int WM, int WN, int WK, int NMT, int NT, int PF>
+__device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __restrict__ X, const float* __restrict__ XS,
+                                          const int* __restrict__ tabL, int rs, int rss, int wm, int wn, int wk,
+                                          int lane, int wave, int n0, int co0) {
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int tw = a.ntap + 1;
+    const int colbase = co0 + wn * NT * 16;
+    f32x4 acc[NMT > 0 ? NMT : 1][NT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (NMT > 0) {
+        int trow[NMT > 0 ? NMT : 1];           // table row of each of this lane's m-tiles
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) trow[i] = ((wm + i * WM) * 16 + lrow) * tw;
+
+        // ---- conv phases: flattened step q = tap * nch + chunk; B for step q sits at wpk + q * bstride
+        {
+            const int nch = a.Cv >> 4;
+            const int nsteps = a.ntap * nch;
+            const size_t bstride = (size_t)a.Cout_pad * 16;
+            const float* Wl = a.wpk + (size_t)(colbase + lrow) * 16 + kq * 4;
+            f32x4 bring[PF][NT];
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+                if (wk + u * WK < nsteps) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bring[u][t] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(wk + u * WK) * bstride + t * 256);
+                }
+            int ph = wk / nch, ch = wk - ph * nch;
+            int abase[NMT > 0 ? NMT : 1];
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs + kq * 4;
+            for (int q = wk; q < nsteps; q += PF * WK) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int qq = q + u * WK;
+                    if (qq < nsteps) {
+                        f32x4 af[NMT > 0 ? NMT : 1];
+#pragma unroll
+                        for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(X + abase[i] + ch * 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) acc[i][t] = mfma16(af[i][j], bring[u][t][j], acc[i][t]);
+                        if (qq + PF * WK < nsteps) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                bring[u][t] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(qq + PF * WK) * bstride + t * 256);
+                        }
+                        ch += WK;
+                        if (ch >= nch) {          // next tap: new row offsets (wave-uniform branch)
+                            ch -= nch; ++ph;
+                            if (ph < a.ntap) {
+#pragma unroll
+                                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs + kq * 4;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- NIN shortcut phase over the raw block input
+        if (a.Csc) {
+            const int nch = a.Csc >> 4;
+            const size_t bstride = (size_t)a.Cout_pad * 16;
+            const float* Wl = a.wsc + (size_t)(colbase + lrow) * 16 + kq * 4;
+            int abase[NMT > 0 ? NMT : 1];
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + a.ntap] * rss + kq * 4;
+            f32x4 bcur[NT], bnext[NT];
+            if (wk < nch) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bcur[t] = *reinterpret_cast<const f32x4*>(Wl + (size_t)wk * bstride + t * 256);
+            }
+            for (int ch = wk; ch < nch; ch += WK) {
+                if (ch + WK < nch) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(ch + WK) * bstride + t * 256);
+                }
+                f32x4 af[NMT > 0 ? NMT : 1];
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(XS + abase[i] + ch * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[i][t] = mfma16(af[i][j], bcur[t][j], acc[i][t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bcur[t] = bnext[t];
+            }
+        }
+    }
+
+    // ---- split-K across waves: reduce through LDS (the input tile is dead by now)
+    if (WK > 1) {
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(rdmi_lds);
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) red[(((wave * (NMT > 0 ? NMT : 1)) + i) * NT + t) * 64 + lane] = acc[i][t];
+        }
+        __syncthreads();
+        if (wk == 0) {
+            for (int k = 1; k < WK; ++k) {
+                const int ow = wave + k;    // waves with the same (wm, wn) are consecutive in wk
+#pragma unroll
+                for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[i][t] += red[(((ow * (NMT > 0 ? NMT : 1)) + i) * NT + t) * 64 + lane];
+            }
+        }
+    }
+
+    // ---- epilogue: bias (+ NIN bias) (+ Dense_0(temb)) (+ identity residual), scale, store NHWC
+    if (wk == 0) {
+        const int rows = a.S * a.HWo;
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+            const int mt = wm + i * WM;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = colbase + t * 16 + lrow;
+                if (col >= a.Cout) continue;
+                float add = a.bias[col];
+                if (a.bias_sc) add += a.bias_sc[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    if (row >= rows) continue;
+                    int s = 0, rr = row;
+                    while (rr >= a.HWo) { rr -= a.HWo; ++s; }
+                    const int n = n0 + s;
+                    if (n >= a.NB) continue;
+                    const size_t o = ((size_t)n0 * a.HWo + row) * a.Cout + col;
+                    float v = acc[i][t][r] + add;
+                    if (a.dense) v += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
+                    if (a.resid) v += a.resid[o];
+                    a.out[o] = v * a.out_scale;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int WK, int MT, int NT, int PF>
 __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = lane & 15, kq = lane >> 4;
+    static_assert(WK == 1 || MT == 1, "split-K waves all own the same single row tile");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> scalar registers, scalar branches
     const int n0 = blockIdx.x * a.S;
     const int co0 = blockIdx.y * a.BN;
 
@@ -120,134 +281,62 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
         const int T = RDMI_THREADS / pairs;        // lanes cooperating on one (sample, group)
         const int pair = tid / T, sub = tid - pair * T;
         const int s = pair / G, g = pair - s * G;
-        const int cnt = Cg * a.HWv;
+        const float inv_cnt = 1.0f / (float)(Cg * a.HWv);
         const float* base = X + (size_t)s * a.HWv * rs + g * Cg;
         float sum = 0.f;
-        for (int e = sub; e < cnt; e += T) {
-            const int v = e / Cg, cc = e - v * Cg;
-            sum += base[(size_t)v * rs + cc];
-        }
+        for (int v = sub; v < a.HWv; v += T)
+            for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * rs + cc];
         for (int m = T >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-        const float mean = sum / (float)cnt;
+        const float mean = sum * inv_cnt;
         float sq = 0.f;
-        for (int e = sub; e < cnt; e += T) {
-            const int v = e / Cg, cc = e - v * Cg;
-            const float d = base[(size_t)v * rs + cc] - mean;
-            sq += d * d;
-        }
+        for (int v = sub; v < a.HWv; v += T)
+            for (int cc = 0; cc < Cg; ++cc) {
+                const float d = base[(size_t)v * rs + cc] - mean;
+                sq += d * d;
+            }
         for (int m = T >> 1; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
         if (sub == 0) {
             stat[2 * pair] = mean;
-            stat[2 * pair + 1] = 1.0f / sqrtf(sq / (float)cnt + a.eps);
+            stat[2 * pair + 1] = 1.0f / sqrtf(sq * inv_cnt + a.eps);
         }
         __syncthreads();
+        // normalise: a work-item keeps its float4 channel column (fixed gamma/beta/group) and walks pixels
         const int c4n = a.Cv >> 2;
         const int total = a.S * a.HWv * c4n;
+        const int dpv = RDMI_THREADS / c4n, dc4 = RDMI_THREADS - dpv * c4n;
+        int pv = tid / c4n, c4 = tid - pv * c4n;
         for (int i = tid; i < total; i += RDMI_THREADS) {
-            const int pv = i / c4n, c = (i - pv * c4n) << 2;
-            const int ss = pv / a.HWv;
+            const int c = c4 << 2;
+            int ss = 0, v = pv;
+            while (v >= a.HWv) { v -= a.HWv; ++ss; }
             float* p = X + (size_t)pv * rs + c;
-            f32x4 v = *reinterpret_cast<f32x4*>(p);
+            f32x4 val = *reinterpret_cast<f32x4*>(p);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
+            int gg = c / Cg, left = Cg - (c - gg * Cg);       // channels left in the current group
             for (int j = 0; j < 4; ++j) {
-                const int gg = (c + j) / Cg;
+                if (left == 0) { ++gg; left = Cg; }
                 const float mu = stat[2 * (ss * G + gg)], rstd = stat[2 * (ss * G + gg) + 1];
-                v[j] = silu_f((v[j] - mu) * rstd * a.gamma[c + j] + a.beta[c + j]);
+                val[j] = silu_f((val[j] - mu) * rstd * gm[j] + bt[j]);
+                --left;
             }
-            *reinterpret_cast<f32x4*>(p) = v;
+            *reinterpret_cast<f32x4*>(p) = val;
+            pv += dpv; c4 += dc4;
+            if (c4 >= c4n) { c4 -= c4n; ++pv; }
         }
     }
     __syncthreads();
 
-    // ---- stage 3: implicit GEMM on MFMA
+    // ---- stage 3/4: GEMM + epilogue, specialised on this wave's (uniform) number of row tiles
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int mtiles = a.Mpad >> 4;
-    const int colbase = co0 + wn * NT * 16;
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nphase = a.ntap + (a.Csc ? 1 : 0);
-    for (int ph = 0; ph < nphase; ++ph) {
-        const bool sc = ph >= a.ntap;
-        const float* L = sc ? XS : X;
-        const int lrs = sc ? rss : rs;
-        const int nch = (sc ? a.Csc : a.Cv) >> 4;
-        const float* W = sc ? a.wsc : a.wpk + (size_t)ph * nch * a.Cout_pad * 16;
-        int abase[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mt = wm + i * WM;
-            abase[i] = (mt < mtiles) ? tabL[(mt * 16 + lrow) * tw + ph] * lrs + kq * 4 : 0;
-        }
-        for (int ch = wk; ch < nch; ch += WK) {
-            f32x4 bf[NT], af[MT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                bf[t] = *reinterpret_cast<const f32x4*>(W + ((size_t)ch * a.Cout_pad + colbase + t * 16 + lrow) * 16 + kq * 4);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(L + abase[i] + ch * 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    if (wm + i * WM < mtiles) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[i][t] = mfma16(af[i][j], bf[t][j], acc[i][t]);
-                    }
-        }
+    const int nmt = mtiles > wm ? (mtiles - wm + WM - 1) / WM : 0;
+#define RDMI_CASE(K)                                                                                         \
+    case K:                                                                                                  \
+        if (K <= MT) conv_gemm<WM, WN, WK, (K <= MT ? K : 0), NT, PF>(a, X, XS, tabL, rs, rss, wm, wn, wk, lane, wave, n0, co0); \
+        break;
+    switch (nmt) {
+        RDMI_CASE(0) RDMI_CASE(1) RDMI_CASE(2) RDMI_CASE(3) RDMI_CASE(4) RDMI_CASE(5) RDMI_CASE(6)
+        default: break;
     }
-
-    // ---- split-K across waves: reduce through LDS (the input tile is dead by now)
-    if (WK > 1) {
-        __syncthreads();
-        f32x4* red = reinterpret_cast<f32x4*>(rdmi_lds);
-        if (wk > 0) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) red[(((wave * MT) + i) * NT + t) * 64 + lane] = acc[i][t];
-        }
-        __syncthreads();
-        if (wk == 0) {
-            for (int k = 1; k < WK; ++k) {
-                const int ow = wave + k;    // waves with the same (wm, wn) are consecutive in wk
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[i][t] += red[(((ow * MT) + i) * NT + t) * 64 + lane];
-            }
-        }
-    }
-
-    // ---- stage 4: epilogue
-    if (wk == 0) {
-        const int rows = a.S * a.HWo;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mt = wm + i * WM;
-            if (mt >= mtiles) continue;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int col = colbase + t * 16 + lrow;
-                if (col >= a.Cout) continue;
-                float add = a.bias[col];
-                if (a.bias_sc) add += a.bias_sc[col];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = mt * 16 + kq * 4 + r;
-                    if (row >= rows) continue;
-                    const int s = row / a.HWo;
-                    const int n = n0 + s;
-                    if (n >= a.NB) continue;
-                    const size_t o = ((size_t)n0 * a.HWo + row) * a.Cout + col;
-                    float v = acc[i][t][r] + add;
-                    if (a.dense) v += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
-                    if (a.resid) v += a.resid[o];
-                    a.out[o] = v * a.out_scale;
-                }
-            }
-        }
-    }
+#undef RDMI_CASE
 }

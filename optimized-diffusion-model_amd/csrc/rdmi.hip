@@ -634,10 +634,10 @@ void prof_collect(rdmi_ctx* c) {
     c->ev_used = 0;
 }
 
-template <int WM, int WN, int WK, int MT, int NT>
+template <int WM, int WN, int WK, int MT, int NT, int PF>
 int launch_conv_t(const ConvArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    auto k = conv_mfma_kernel<WM, WN, WK, MT, NT>;
+    auto k = conv_mfma_kernel<WM, WN, WK, MT, NT, PF>;
     if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     dim3 grid((unsigned)ceil_div(a.NB, a.S), (unsigned)(a.Cout_pad / a.BN));
     hipLaunchKernelGGL(k, grid, dim3(RDMI_THREADS), conv_lds_bytes(a), s, a);
@@ -647,10 +647,10 @@ int launch_conv_t(const ConvArgs& a, hipStream_t s) {
 
 int launch_conv(int cfg, const ConvArgs& a, hipStream_t s) {
     switch (cfg) {
-        case 0: return launch_conv_t<1, 4, 1, 6, 1>(a, s);
-        case 1: return launch_conv_t<2, 2, 1, 3, 1>(a, s);
-        case 2: return launch_conv_t<1, 2, 2, 1, 1>(a, s);
-        case 3: return launch_conv_t<4, 1, 1, 2, 1>(a, s);
+        case 0: return launch_conv_t<1, 4, 1, 6, 1, 2>(a, s);
+        case 1: return launch_conv_t<2, 2, 1, 3, 1, 3>(a, s);
+        case 2: return launch_conv_t<1, 2, 2, 1, 1, 6>(a, s);
+        case 3: return launch_conv_t<4, 1, 1, 2, 1, 4>(a, s);
     }
     return fail("bad conv cfg %d", cfg);
 }

@@ -179,16 +179,26 @@ def _fusable(sde, model, predictor, corrector):
 
 
 def get_pc_sampler(sde, shape, predictor, corrector, denoiser, snr, n_steps=1, eps=1e-3, device='cuda',
-                   noise=None, seed=None, seq_offset=0, trace=None, teacher=None, fused=True):
+                   noise=None, seed=None, seq_offset=0, trace=None, teacher=None, fused=True, shard=None):
     """RD/sampling.py:292-339.  Extra keyword-only knobs (not in the reference) for parity testing and sharding:
     noise: 'torch' (per-update torch.randn_like on `device`, the reference's RNG consumption), a tensor
     [(N-1)*(n_corr+1), B, H*W] of injected draws, or None = in-kernel Philox keyed by (seed, seq_offset);
-    trace / teacher: per-update recording / teacher forcing buffers [N-1, B, H*W]; fused=False forces the generic loop."""
+    trace / teacher: per-update recording / teacher forcing buffers [N-1, B, H*W]; fused=False forces the generic loop;
+    shard=(rank, world): `shape` is this rank's slice of a global batch of world*shape[0]: the prior is drawn for the
+    global batch and sliced and the Philox stream is offset, so the shards reproduce the unsharded run."""
+
+    def draw_prior():
+        if shard is None:
+            return torch.rand(shape)
+        r, w = shard
+        return torch.rand((w * shape[0],) + tuple(shape[1:]))[r * shape[0]:(r + 1) * shape[0]].contiguous()
+
+    off = seq_offset if shard is None else seq_offset + shard[0] * shape[0]
 
     def pc_sampler(model, z=None, noise_removal_model=None, weight=0, class_labels=None):
         # F5 (SURVEY): the reference draws the prior, builds the score fn, then draws the prior AGAIN inside
         # no_grad and ignores z; the denoiser's result is discarded and the noisy x is returned.
-        x = torch.rand(shape).to(device) if z is None else z
+        x = draw_prior().to(device) if z is None else z
         if class_labels is None:
             score_fn = mutils.get_score_fn(sde, model, train=False)
         else:
@@ -198,10 +208,10 @@ def get_pc_sampler(sde, shape, predictor, corrector, denoiser, snr, n_steps=1, e
         deno = denoiser(noise_removal_model)
 
         with torch.no_grad():
-            x = torch.rand(shape).to(device)
+            x = draw_prior().to(device)
             if fused and _fusable(sde, model, predictor, corrector) and not isinstance(noise, str):
                 x = _fused_pc(sde, model, x, class_labels, weight, corrector is ReflectedLangevinCorrector, snr, n_steps,
-                              eps, noise, seed, seq_offset, trace, teacher)
+                              eps, noise, seed, off, trace, teacher)
             else:
                 timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
                 x_mean = x

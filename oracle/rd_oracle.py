@@ -143,27 +143,28 @@ def group_norm(x, gamma, beta, eps=1e-6):
 
 
 def conv3x3(x, w, b, stride=1, padding=1):
-    """RD/models/layers.py:103-109 -- nn.Conv2d(k=3), weights OIHW; im2col + one GEMM."""
+    """RD/models/layers.py:103-109 -- nn.Conv2d(k=3), weights OIHW; im2col (NHWC) + one GEMM."""
     B, C, H, W = x.shape
     O = w.shape[0]
+    xh = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
     if padding:
-        x = np.pad(x, ((0, 0), (0, 0), (padding, padding), (padding, padding)))
-    Hp, Wp = x.shape[2:]
+        xh = np.pad(xh, ((0, 0), (padding, padding), (padding, padding), (0, 0)))
+    Hp, Wp = xh.shape[1:3]
     Ho, Wo = (Hp - 3) // stride + 1, (Wp - 3) // stride + 1
     cols = np.empty((B, Ho, Wo, 9, C), F32)
     for dy in range(3):
         for dx in range(3):
-            v = x[:, :, dy:dy + (Ho - 1) * stride + 1:stride, dx:dx + (Wo - 1) * stride + 1:stride]
-            cols[:, :, :, dy * 3 + dx, :] = v.transpose(0, 2, 3, 1)
-    wm = w.transpose(2, 3, 1, 0).reshape(9 * C, O)           # [(tap, c), o]
+            cols[:, :, :, dy * 3 + dx, :] = xh[:, dy:dy + (Ho - 1) * stride + 1:stride, dx:dx + (Wo - 1) * stride + 1:stride, :]
+    wm = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(9 * C, O))           # [(tap, c), o]
     y = cols.reshape(B * Ho * Wo, 9 * C) @ wm + b
-    return y.reshape(B, Ho, Wo, O).transpose(0, 3, 1, 2).astype(F32)
+    return np.ascontiguousarray(y.reshape(B, Ho, Wo, O).transpose(0, 3, 1, 2), dtype=F32)
 
 
 def nin(x, W, b):
     """RD/models/layers.py:531-540 -- channel matmul, W is [in, out]."""
-    y = np.einsum('bchw,co->bohw', x, W, optimize=True) + b.reshape(1, -1, 1, 1)
-    return y.astype(F32)
+    B, C, H, Wd = x.shape
+    y = x.transpose(0, 2, 3, 1).reshape(-1, C) @ W + b
+    return np.ascontiguousarray(y.reshape(B, H, Wd, -1).transpose(0, 3, 1, 2), dtype=F32)
 
 
 def nearest_resize(x, Ho, Wo):
@@ -187,10 +188,10 @@ def attn_block(p, pre, x):
     q = nin(h, p[pre + 'NIN_0.W'], p[pre + 'NIN_0.b']).reshape(B, C, H * W)
     k = nin(h, p[pre + 'NIN_1.W'], p[pre + 'NIN_1.b']).reshape(B, C, H * W)
     v = nin(h, p[pre + 'NIN_2.W'], p[pre + 'NIN_2.b']).reshape(B, C, H * W)
-    w = np.einsum('bcq,bck->bqk', q, k, optimize=True) * F32(int(C) ** (-0.5))
+    w = np.matmul(q.transpose(0, 2, 1), k) * F32(int(C) ** (-0.5))
     w = w - w.max(-1, keepdims=True)
     w = np.exp(w); w = (w / w.sum(-1, keepdims=True, dtype=F32)).astype(F32)
-    h = np.einsum('bqk,bck->bcq', w, v, optimize=True).reshape(B, C, H, W).astype(F32)
+    h = np.matmul(v, w.transpose(0, 2, 1)).reshape(B, C, H, W).astype(F32)
     h = nin(h, p[pre + 'NIN_3.W'], p[pre + 'NIN_3.b'])
     return ((x + h) / F32(np.sqrt(2.))).astype(F32)
 

@@ -95,3 +95,27 @@ def test_train_loss(golden, params0):
     sde = O.RVESDE(0.01, 5, N=1000)
     loss, *_ = O.sde_loss(params0, sde, g['batch'], g['labels'], g['step0.t'], g['step0.z'])
     close(loss, g['step0.loss'], rtol=2e-4, atol=0)
+
+
+def test_torch_flavour_oracle(golden, params0):
+    """oracle/rd_oracle_torch.py (the cpu_baseline leg of bench.py) against the reference fixtures."""
+    import torch
+    from oracle import rd_oracle_torch as OT
+    p = {k: torch.from_numpy(v) for k, v in params0.items()}
+    g = golden('forward_9x9.npz')
+    x, t, lab = (torch.from_numpy(g[k]) for k in ('x', 't', 'labels'))
+    with torch.no_grad():
+        close(OT.ncsnpp_forward(p, x, OT.sigma_of(t), lab).numpy(), g['score'], rtol=1e-4, atol=1e-4)
+        close(OT.cf_score(p, x, t, lab, torch.from_numpy(g['wt'])).numpy(), g['cf_wt'], rtol=1e-4, atol=2e-4)
+    gs = golden('sampler_10step.npz')
+    ts = O.torch_linspace(1, 1e-5, 10)
+    steps, nz = gs['langevin_w0.steps'], gs['langevin_w0.noises']
+    xcur = torch.from_numpy(gs['langevin_w0.prior'])
+    amp = np.maximum(1.0, O.RVESDE(0.01, 5, N=10).g(ts[:9]) ** 2 / 10)
+    with torch.no_grad():
+        for i in range(9):
+            tt = torch.full((8,), float(ts[i]))
+            xn = OT.pc_update(p, xcur, tt, torch.from_numpy(gs['labels']), torch.zeros(8), torch.from_numpy(nz[2 * i + 1]), 10,
+                              z_corr=torch.from_numpy(nz[2 * i]))
+            close(xn.numpy(), steps[i], rtol=0, atol=2e-5 * amp[i])
+            xcur = torch.from_numpy(steps[i])
