@@ -141,6 +141,9 @@ int rdmi_set_profiling(rdmi_ctx* ctx, int enabled);
 int rdmi_get_profile(rdmi_ctx* ctx, int index, const char** kernel_name, double* total_ms, long* launches,
                      double* flops_per_launch);
 
+/* Which execution plan the context uses ("fused: ..." or "layers: ... (reason)"). */
+const char* rdmi_path_info(rdmi_ctx* ctx);
+
 const char* rdmi_last_error(void);
 const char* rdmi_version(void);
 

@@ -19,6 +19,7 @@
 #include "attn_kernel.h"
 #include "conv_kernel.h"
 #include "misc_kernels.h"
+#include "unet_kernel.h"
 
 namespace {
 
@@ -108,6 +109,18 @@ struct rdmi_ctx {
     float *d_s2 = nullptr, *d_score = nullptr, *d_z = nullptr, *d_norms = nullptr, *d_ts = nullptr, *d_tvec = nullptr;
     int ts_cap = 0;
     StepState* d_state = nullptr;
+    // fused (workgroup-resident) path
+    bool fused_ok = false, use_fused = true;
+    std::string fused_why;               // why the fused program could not be built (falls back to the layer plan)
+    std::vector<FOp> fprog;              // host copy; parameter pointers are patched at repack time
+    struct FPatch { int op; int field; std::string param; size_t arena_off; };
+    std::vector<FPatch> fpatch;
+    std::vector<short> ftabs;
+    FOp* d_fprog = nullptr; short* d_ftabs = nullptr;
+    float* d_spill = nullptr; size_t spill_per_sample = 0;
+    UnetArgs fargs{};
+    size_t fused_lds = 0;
+    std::map<std::string, size_t> wmap;  // packed-weight arena offsets by parameter prefix
     bool packed_valid = false;
     bool debug_taps = false;
     bool profiling = false;
@@ -259,6 +272,7 @@ struct Builder {
         const int Kp = pad16(cin), Np = pad16(cout);
         size_t o = alloc_w((size_t)9 * Kp * Np);
         job_pack(pre + ".weight", o, cin, cout, Kp, Np, 0, 9, (long)cin * 9, 9, 1);
+        c->wmap[pre] = o;
         return o;
     }
     // NIN W [in][out] -> [Kpad/16][Npad][16]
@@ -266,6 +280,7 @@ struct Builder {
         const int Kp = pad16(cin), Np = pad16(cout);
         size_t o = alloc_w((size_t)Kp * Np);
         job_pack(pre + ".W", o, cin, cout, Kp, Np, 0, 1, 1, cout, 0);
+        c->wmap[pre] = o;
         return o;
     }
 
@@ -384,7 +399,9 @@ struct Builder {
             c->jobs.push_back(j);
             c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
         }
+        c->wmap[name + ".qkv"] = op.w_off;
         op.bqkv_off = alloc_w((size_t)3 * C);
+        c->wmap[name + ".bqkv"] = op.bqkv_off;
         for (int i = 0; i < 3; ++i) job_copy(name + ".NIN_" + std::to_string(i) + ".b", op.bqkv_off, C, i * C);
         op.w3_off = pack_nin(name + ".NIN_3", C, C);
         op.p_b3 = name + ".NIN_3.b";
@@ -422,6 +439,8 @@ int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, in
     }
     return b.add_conv(s1, err);
 }
+
+int build_fused_program(rdmi_ctx* c);
 
 int build_plan(rdmi_ctx* c) {
     const rdmi_arch& a = c->arch;
@@ -598,6 +617,395 @@ int build_plan(rdmi_ctx* c) {
             aa.wqkv = c->d_w + op.w_off; aa.bqkv = c->d_w + op.bqkv_off; aa.w3 = c->d_w + op.w3_off;
         }
     }
+    return build_fused_program(c);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused program (workgroup-resident U-Net, csrc/unet_kernel.h)
+// ------------------------------------------------------------------------------------------
+struct FusedBuilder {
+    rdmi_ctx* c;
+    static constexpr int LDS_TOTAL = 160 * 1024;
+    struct Blk { int off, size; };
+    std::vector<Blk> freel;
+    int arena_lo = 0, high_water = 0;
+    std::map<std::string, int> tabcache;       // geometry key -> offset (in shorts) into ftabs
+    struct LT { int off = -1, C = 0, H = 0, W = 0, rs = 0, bytes = 0; int rows() const { return H * W; } };
+    size_t spill_floats = 0;
+    bool failed = false;
+    std::string why;
+
+    void fail_(const std::string& m) { if (!failed) { failed = true; why = m; } }
+
+    // ---- LDS arena: first-fit with coalescing free list
+    void arena_init(int lo) { arena_lo = lo; freel.clear(); freel.push_back({lo, LDS_TOTAL - lo}); high_water = lo; }
+    int alloc_bytes(int n) {
+        n = (n + 15) & ~15;
+        for (size_t i = 0; i < freel.size(); ++i)
+            if (freel[i].size >= n) {
+                const int o = freel[i].off;
+                freel[i].off += n; freel[i].size -= n;
+                if (freel[i].size == 0) freel.erase(freel.begin() + (long)i);
+                high_water = std::max(high_water, o + n);
+                return o;
+            }
+        {
+            std::string fl;
+            for (auto& f : freel) fl += " [" + std::to_string(f.off) + "+" + std::to_string(f.size) + "]";
+            fail_("LDS arena exhausted at op " + std::to_string(c->fprog.size()) + " (need " + std::to_string(n) + " B; free:" + fl + ")");
+        }
+        return arena_lo;
+    }
+    int alloc_top(int n) {                      // odd-sized scratch (Vt, P): carve from the END of the highest block that fits
+        n = (n + 15) & ~15;
+        for (size_t k = freel.size(); k-- > 0;)
+            if (freel[k].size >= n) {
+                const int o = freel[k].off + freel[k].size - n;
+                freel[k].size -= n;
+                if (freel[k].size == 0) freel.erase(freel.begin() + (long)k);
+                high_water = std::max(high_water, o + n);
+                return o;
+            }
+        return alloc_bytes(n);
+    }
+    void free_bytes(int off, int n) {
+        n = (n + 15) & ~15;
+        freel.push_back({off, n});
+        std::sort(freel.begin(), freel.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < freel.size();)
+            if (freel[i].off + freel[i].size == freel[i + 1].off) { freel[i].size += freel[i + 1].size; freel.erase(freel.begin() + (long)i + 1); }
+            else ++i;
+    }
+    LT talloc(int C, int H, int W) {
+        LT t; t.C = C; t.H = H; t.W = W; t.rs = C + 4; t.bytes = H * W * t.rs * 4; t.off = alloc_bytes(t.bytes);
+        return t;
+    }
+    void tfree(LT& t) { if (t.off >= 0) free_bytes(t.off, t.bytes); t.off = -1; }
+
+    // ---- row tables (int16), deduplicated by geometry
+    int add_table(const std::string& key, const std::vector<short>& v) {
+        auto it = tabcache.find(key);
+        if (it != tabcache.end()) return it->second;
+        while (c->ftabs.size() % 2) c->ftabs.push_back(-1);
+        const int off = (int)c->ftabs.size();
+        c->ftabs.insert(c->ftabs.end(), v.begin(), v.end());
+        tabcache[key] = off;
+        return off;
+    }
+    // tap table of a conv reading tensor (Hs x Ws) seen as a virtual (Hv x Wv) grid (nearest), output (Ho x Wo)
+    int tap_table(int Hs, int Ws, int Hv, int Wv, int Ho, int Wo, int stride, int pad_lo, int tap) {
+        char key[128];
+        snprintf(key, sizeof key, "tap:%d,%d,%d,%d,%d,%d,%d,%d,%d", Hs, Ws, Hv, Wv, Ho, Wo, stride, pad_lo, tap);
+        const int Mpad = pad16(Ho * Wo);
+        std::vector<short> v((size_t)Mpad, (short)-1);
+        for (int m = 0; m < Ho * Wo; ++m) {
+            const int oy = m / Wo, ox = m % Wo;
+            const int iy = oy * stride + tap / 3 - pad_lo, ix = ox * stride + tap % 3 - pad_lo;
+            if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) continue;
+            const int sy = std::min((int)std::floor(iy * ((float)Hs / Hv)), Hs - 1);
+            const int sx = std::min((int)std::floor(ix * ((float)Ws / Wv)), Ws - 1);
+            v[(size_t)m] = (short)(sy * Ws + sx);
+        }
+        return add_table(key, v);
+    }
+    int ident_table(int M) {
+        const int Mpad = pad16(M);
+        std::vector<short> v((size_t)Mpad, (short)-1);
+        for (int m = 0; m < M; ++m) v[(size_t)m] = (short)m;
+        return add_table("id:" + std::to_string(M), v);
+    }
+    int map_table(int Hs, int Ws, int Hd, int Wd) {      // nearest map as a GATHER row map
+        std::vector<short> v((size_t)Hd * Wd);
+        for (int y = 0; y < Hd; ++y)
+            for (int x = 0; x < Wd; ++x) {
+                const int sy = std::min((int)std::floor(y * ((float)Hs / Hd)), Hs - 1);
+                const int sx = std::min((int)std::floor(x * ((float)Ws / Wd)), Ws - 1);
+                v[(size_t)y * Wd + x] = (short)(sy * Ws + sx);
+            }
+        char key[64];
+        snprintf(key, sizeof key, "map:%d,%d,%d,%d", Hs, Ws, Hd, Wd);
+        return add_table(key, v);
+    }
+
+    // ---- op emission.  Table offsets are emitted in SHORTS relative to the table region and turned into LDS
+    //      byte offsets once the region's base is known (finish()).
+    FOp blank(int kind) {
+        FOp o;
+        std::memset(&o, 0, sizeof o);
+        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f;
+        return o;
+    }
+    int emit(const FOp& o) { c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
+    enum { F_GAMMA, F_BETA, F_BIAS, F_BIAS2, F_W, F_SC0W, F_SC1W, F_BIAS_ARENA };
+    void patch_param(int op, int field, const std::string& param) { c->fpatch.push_back({op, field, param, 0}); }
+    void patch_arena(int op, int field, size_t off) { c->fpatch.push_back({op, field, "", off}); }
+
+    void gather_x(const LT& dst) {               // network input -> LDS [HW][16+4]
+        FOp o = blank(FOP_GATHER);
+        o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
+        o.CA = c->arch.channels; o.CB = 0; o.a_off = -2; o.a_hw = dst.rows();
+        emit(o);
+    }
+    // dst = concat(A (LDS tensor, nearest-mapped onto dst's grid), B (global spill slot))
+    void gather_cat(const LT& dst, const LT& A, size_t spillB, int CB) {
+        FOp o = blank(FOP_GATHER);
+        o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
+        o.CA = A.C; o.CB = CB; o.a_off = A.off; o.a_rs = A.rs;
+        if (A.H != dst.H || A.W != dst.W) o.a_map_off = map_table(A.H, A.W, dst.H, dst.W);
+        o.b_off = -1; o.b_g = c->d_spill ? nullptr : nullptr;
+        const int idx = emit(o);
+        spill_fix.push_back({idx, spillB, true});
+    }
+    void copy_t(const LT& dst, const LT& src) {
+        FOp o = blank(FOP_GATHER);
+        o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
+        o.CA = src.C; o.CB = 0; o.a_off = src.off; o.a_rs = src.rs;
+        emit(o);
+    }
+    struct SpillFix { int op; size_t off; bool is_b; };
+    std::vector<SpillFix> spill_fix;
+    size_t spill_store(const LT& t) {            // LDS tensor -> this workgroup's slot of the spill buffer
+        FOp o = blank(FOP_STORE);
+        o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
+        const int idx = emit(o);
+        const size_t off = spill_floats;
+        spill_floats += (size_t)t.rows() * t.C;
+        spill_fix.push_back({idx, off, false});
+        return off;
+    }
+    void gn(const LT& t, const std::string& pre, bool act) {
+        FOp o = blank(FOP_GN);
+        o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
+        o.G = std::min(t.C / 4, 32); o.act = act ? 1 : 0; o.eps = 1e-6f;
+        if (t.C % o.G != 0 || UW_THREADS % o.G != 0 || UW_THREADS / o.G > 64) fail_("GroupNorm shape C=" + std::to_string(t.C));
+        const int idx = emit(o);
+        patch_param(idx, F_GAMMA, pre + ".weight"); patch_param(idx, F_BETA, pre + ".bias");
+    }
+    struct ConvOut { int kind; LT* t; };
+    // 3x3 conv (or 1x1 when ntap == 1) over LDS tensor `in`
+    int conv(const LT& in, int Hv, int Wv, int Ho, int Wo, int stride, int pad_lo, int ntap, const std::string& wkey,
+             size_t w_extra_off, int Cout, const std::string& bias_param, size_t bias_arena, int dst_kind, const LT* dst,
+             float scale, int dense_off, const LT* resid, const LT* sc_src, const std::string& sc_key,
+             const std::string& bias2_param) {
+        FOp o = blank(FOP_CONV);
+        o.rows = Ho * Wo; o.mtiles = pad16(Ho * Wo) / 16; o.Cout = Cout; o.Cout_pad = pad16(Cout);
+        o.ntap = ntap;
+        o.main_ph.lds_off = in.off; o.main_ph.rs = in.rs; o.main_ph.nch = pad16(in.C) / 16;
+        if (in.C % 16 != 0) fail_("conv input channels not padded");
+        for (int t = 0; t < ntap; ++t)
+            o.tab_off[t] = ntap == 1 ? ident_table(Ho * Wo) : tap_table(in.H, in.W, Hv, Wv, Ho, Wo, stride, pad_lo, t);
+        o.dense_off = dense_off; o.scale = scale; o.dst_kind = dst_kind;
+        if (dst) { o.dst_off = dst->off; o.dst_rs = dst->rs; }
+        if (resid) { o.resid_off = resid->off; o.resid_rs = resid->rs; }
+        if (o.mtiles > 6) fail_("conv with more than 96 output pixels per sample");
+        if (sc_src) {
+            o.nsc = 1;
+            o.sc[0].lds_off = sc_src->off; o.sc[0].rs = sc_src->rs; o.sc[0].nch = sc_src->C / 16; o.sc[0].tab_off = ident_table(Ho * Wo);
+        }
+        const int idx = emit(o);
+        patch_arena(idx, F_W, c->wmap.at(wkey) + w_extra_off);
+        if (!bias_param.empty()) patch_param(idx, F_BIAS, bias_param); else patch_arena(idx, F_BIAS_ARENA, bias_arena);
+        if (sc_src) { patch_arena(idx, F_SC0W, c->wmap.at(sc_key)); patch_param(idx, F_BIAS2, bias2_param); }
+        return idx;
+    }
+};
+
+// ResnetBlockDDPMpp on LDS tensors.  xin: raw block input (consumed).  Returns the block output.
+// When the block has a NIN shortcut (cin != cout, i.e. every concat-fed up block) the shortcut is evaluated FIRST
+// into the output buffer, so GroupNorm_0 can then run in place on xin: no second copy of the (large) concat
+// tensor is ever resident.  Identity-shortcut blocks keep xin raw for the residual and normalise a copy.
+FusedBuilder::LT fused_resblock(FusedBuilder& b, const std::string& name, FusedBuilder::LT& xin, int cout, int dense_off) {
+    using LT = FusedBuilder::LT;
+    const int H = xin.H, W = xin.W;
+    const float rs2 = (float)(1.0 / std::sqrt(2.0));
+    if (xin.C != cout) {
+        LT out = b.talloc(cout, H, W);
+        b.conv(xin, H, W, H, W, 1, 0, 1, name + ".NIN_0", 0, cout, name + ".NIN_0.b", 0, 0, &out, 1.f, -1, nullptr, nullptr, "", "");
+        b.gn(xin, name + ".GroupNorm_0", true);
+        LT h1 = b.talloc(cout, H, W);
+        b.conv(xin, H, W, H, W, 1, 1, 9, name + ".Conv_0", 0, cout, name + ".Conv_0.bias", 0, 0, &h1, 1.f, dense_off, nullptr, nullptr, "", "");
+        b.tfree(xin);
+        b.gn(h1, name + ".GroupNorm_1", true);
+        b.conv(h1, H, W, H, W, 1, 1, 9, name + ".Conv_1", 0, cout, name + ".Conv_1.bias", 0, 0, &out, rs2, -1, &out, nullptr, "", "");
+        b.tfree(h1);
+        return out;
+    }
+    LT xact = b.talloc(xin.C, H, W);
+    b.copy_t(xact, xin);
+    b.gn(xact, name + ".GroupNorm_0", true);
+    LT h1 = b.talloc(cout, H, W);
+    b.conv(xact, H, W, H, W, 1, 1, 9, name + ".Conv_0", 0, cout, name + ".Conv_0.bias", 0, 0, &h1, 1.f, dense_off, nullptr, nullptr, "", "");
+    b.tfree(xact);
+    b.gn(h1, name + ".GroupNorm_1", true);
+    LT out = b.talloc(cout, H, W);
+    b.conv(h1, H, W, H, W, 1, 1, 9, name + ".Conv_1", 0, cout, name + ".Conv_1.bias", 0, 0, &out, rs2, -1, &xin, nullptr, "", "");
+    b.tfree(h1);
+    b.tfree(xin);
+    return out;
+}
+
+// AttnBlockpp on an LDS tensor (consumed).  Returns the block output.
+FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuilder::LT& x) {
+    using LT = FusedBuilder::LT;
+    rdmi_ctx* c = b.c;
+    const int C = x.C, H = x.H, W = x.W, L = H * W, Lpad = pad16(L);
+    if (C != 64 || Lpad > 96) { b.fail_("attention: only C=64, H*W<=96 is built"); return x; }
+    LT xn = b.talloc(C, H, W);
+    b.copy_t(xn, x);
+    b.gn(xn, name + ".GroupNorm_0", false);
+    LT q = b.talloc(C, H, W), k = b.talloc(C, H, W);
+    const int ps = Lpad + 4;
+    const int vt_bytes = C * ps * 4, p_bytes = L * ps * 4;
+    const int vt_off = b.alloc_top(vt_bytes);
+    LT vt; vt.off = vt_off; vt.rs = ps; vt.C = C;
+    const size_t CC = (size_t)C * C;
+    const size_t bq = c->wmap.at(name + ".bqkv");
+    b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv", 0, C, "", bq, 0, &q, 1.f, -1, nullptr, nullptr, "", "");
+    b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv", CC, C, "", bq + C, 0, &k, 1.f, -1, nullptr, nullptr, "", "");
+    b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv", 2 * CC, C, "", bq + 2 * C, 1, &vt, 1.f, -1, nullptr, nullptr, "", "");
+    b.tfree(xn);
+    const int p_off = b.alloc_top(p_bytes);
+    LT o = b.talloc(C, H, W);
+    {
+        FOp a = b.blank(FOP_ATTN);
+        a.q_off = q.off; a.k_off = k.off; a.qk_rs = q.rs; a.vt_off = vt_off; a.p_off = p_off; a.ps = ps;
+        a.L = L; a.Lpad = Lpad; a.C = C; a.att_scale = 1.0f / std::sqrt((float)C);
+        a.dst_off = o.off; a.dst_rs = o.rs;
+        b.emit(a);
+    }
+    b.tfree(q); b.tfree(k);
+    b.free_bytes(vt_off, vt_bytes); b.free_bytes(p_off, p_bytes);
+    LT out = b.talloc(C, H, W);
+    b.conv(o, H, W, H, W, 1, 0, 1, name + ".NIN_3", 0, C, name + ".NIN_3.b", 0, 0, &out, (float)(1.0 / std::sqrt(2.0)), -1, &x, nullptr, "", "");
+    b.tfree(o);
+    b.tfree(x);
+    return out;
+}
+
+int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used);
+
+int build_fused_program(rdmi_ctx* c) {
+    int used = 0;
+    if (int e = build_fused_program_pass(c, 8 * 1024, &used)) return e;
+    if (c->fused_ok) {   // second pass with the table region sized exactly
+        for (void* p : {(void*)c->d_fprog, (void*)c->d_ftabs, (void*)c->d_spill}) if (p) (void)hipFree(p);
+        c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr;
+    }
+    c->fused_ok = false; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); c->fused_why.clear();
+    return build_fused_program_pass(c, (used + 63) & ~63, &used);
+}
+
+int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
+    using LT = FusedBuilder::LT;
+    const rdmi_arch& a = c->arch;
+    FusedBuilder b{c};
+    Layout L = build_layout(c);
+    std::map<std::string, int> dense_off;
+    {
+        int dt = 0;
+        for (auto& d : L.down) { dense_off[d.name] = dt; dt += d.cout; }
+        dense_off["mid_block1"] = dt; dt += L.mid_ch;
+        dense_off["mid_block2"] = dt; dt += L.mid_ch;
+        for (auto& u : L.up) { dense_off[u.name] = dt; dt += u.cout; }
+    }
+    // LDS: [row tables] [zero row] [GN stats] [tensor arena]
+    const int zero_bytes = 1280;                     // >= (Cmax/16)*64 + 64 for Cmax = 256... host-checked below
+    const int stat_bytes = 256;
+    b.arena_init(TAB_RESERVE + zero_bytes + stat_bytes);
+    int H = c->H, W = c->W;
+    if (H * W > 96) { c->fused_why = "more than 96 pixels per sample"; return 0; }
+
+    LT xin = b.talloc(16, H, W);
+    b.gather_x(xin);
+    LT h = b.talloc(a.nf, H, W);
+    b.conv(xin, H, W, H, W, 1, 1, 9, "input_conv", 0, a.nf, "input_conv.bias", 0, 0, &h, 1.f, -1, nullptr, nullptr, "", "");
+    b.tfree(xin);
+    struct HS { size_t spill; int C, H, W; };
+    std::vector<HS> hs;
+    hs.push_back({(size_t)-1, a.nf, H, W});          // hs[0] (input_conv output) is never popped (RD/models/ncsnpp.py:268,315)
+    int ch = a.nf, d = 0;
+    for (int i = 0; i < a.n_levels; ++i) {
+        for (int j = 0; j < a.num_res_blocks; ++j, ++d) {
+            const BlockSpec& bs = L.down[(size_t)d];
+            h = fused_resblock(b, bs.name, h, bs.cout, dense_off[bs.name]);
+            ch = bs.cout;
+            if (bs.attn) h = fused_attn(b, "down_attn." + std::to_string(d), h);
+            hs.push_back({b.spill_store(h), ch, H, W});
+        }
+        hs.push_back(hs.back());
+        if (i != a.n_levels - 1) {
+            const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+            LT o = b.talloc(ch, Ho, Wo);
+            const std::string nm = "downsample." + std::to_string(i) + ".Conv_0";
+            b.conv(h, H, W, Ho, Wo, 2, 0, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
+            b.tfree(h);
+            h = o; H = Ho; W = Wo;
+        }
+    }
+    h = fused_resblock(b, "mid_block1", h, ch, dense_off["mid_block1"]);
+    h = fused_resblock(b, "mid_block2", h, ch, dense_off["mid_block2"]);
+    int u = 0;
+    for (int k = 0; k < a.n_levels; ++k) {
+        for (int j = 0; j < a.num_res_blocks + 1; ++j, ++u) {
+            const BlockSpec& bs = L.up[(size_t)u];
+            HS sk = hs.back();
+            hs.pop_back();
+            LT cat = b.talloc(ch + sk.C, sk.H, sk.W);
+            b.gather_cat(cat, h, sk.spill, sk.C);
+            b.tfree(h);
+            H = sk.H; W = sk.W;
+            h = fused_resblock(b, bs.name, cat, bs.cout, dense_off[bs.name]);
+            ch = bs.cout;
+            if (bs.attn) h = fused_attn(b, "up_attn." + std::to_string(u), h);
+        }
+        if (k != a.n_levels - 1) {
+            LT o = b.talloc(ch, 2 * H, 2 * W);
+            const std::string nm = "upsample." + std::to_string(k) + ".Conv_0";
+            b.conv(h, 2 * H, 2 * W, 2 * H, 2 * W, 1, 1, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
+            b.tfree(h);
+            h = o; H *= 2; W *= 2;
+        }
+    }
+    b.gn(h, "out_norm", true);
+    b.conv(h, H, W, H, W, 1, 1, 9, "out_conv", 0, a.channels, "out_conv.bias", 0, 2, nullptr, 1.f, -1, nullptr, nullptr, "", "");
+    b.tfree(h);
+
+    *tab_used = (int)c->ftabs.size() * 2 + 16;
+    if (*tab_used > TAB_RESERVE && TAB_RESERVE != 8 * 1024) b.fail_("row tables exceed the reserved LDS region");
+    int cmax = 16;
+    for (auto& o : c->fprog) if (o.kind == FOP_CONV) { cmax = std::max(cmax, o.main_ph.nch * 16); for (int s2 = 0; s2 < o.nsc; ++s2) cmax = std::max(cmax, o.sc[s2].nch * 16); }
+    if (cmax * 4 + 64 > zero_bytes) b.fail_("zero row too small");
+    if (b.failed && TAB_RESERVE == 8 * 1024 && *tab_used <= 8 * 1024) { c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); c->fused_ok = false; return 0; }   // pass 1 only sizes the tables
+    if (b.failed) { c->fused_why = b.why; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); return 0; }
+
+    // table offsets (shorts, relative) -> LDS byte offsets
+    for (auto& o : c->fprog) {
+        if (o.kind == FOP_CONV) {
+            for (int t = 0; t < o.ntap; ++t) o.tab_off[t] = o.tab_off[t] * 2;
+            for (int s2 = 0; s2 < o.nsc; ++s2) o.sc[s2].tab_off = o.sc[s2].tab_off * 2;
+        } else if (o.kind == FOP_GATHER && o.a_map_off >= 0) {
+            o.a_map_off = o.a_map_off * 2;
+        }
+    }
+    while (c->ftabs.size() % 8) c->ftabs.push_back(-1);
+    c->spill_per_sample = b.spill_floats;
+    HIP_OK(hipMalloc((void**)&c->d_spill, std::max<size_t>(c->spill_per_sample, 1) * (size_t)c->max_batch * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->d_fprog, c->fprog.size() * sizeof(FOp)));
+    HIP_OK(hipMalloc((void**)&c->d_ftabs, c->ftabs.size() * sizeof(short)));
+    HIP_OK(hipMemcpy(c->d_ftabs, c->ftabs.data(), c->ftabs.size() * sizeof(short), hipMemcpyHostToDevice));
+    // spill slots: [slot][n][rows][C] so a workgroup only ever touches its own sample's rows
+    for (auto& f : b.spill_fix) {
+        FOp& o = c->fprog[(size_t)f.op];
+        float* p = c->d_spill + f.off * (size_t)c->max_batch;
+        if (f.is_b) o.b_g = p; else o.g_out = p;
+    }
+    c->fargs = UnetArgs{};
+    c->fargs.prog = c->d_fprog; c->fargs.nops = (int)c->fprog.size();
+    c->fargs.tabs = c->d_ftabs; c->fargs.tab_bytes = (int)(c->ftabs.size() * sizeof(short)); c->fargs.tab_base = 0;
+    c->fargs.zero_off = TAB_RESERVE; c->fargs.zero_bytes = zero_bytes;
+    c->fargs.dense = c->d_dense; c->fargs.dense_stride = c->dense_total;
+    c->fused_lds = (size_t)b.high_water;
+    c->fused_ok = true;
     return 0;
 }
 
@@ -698,6 +1106,23 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
             op.attn.gamma = P(c, op.p_gamma); op.attn.beta = P(c, op.p_beta); op.attn.b3 = P(c, op.p_b3);
         }
     }
+    if (c->fused_ok) {
+        for (auto& f : c->fpatch) {
+            FOp& o = c->fprog[(size_t)f.op];
+            const float* p = f.param.empty() ? c->d_w + f.arena_off : P(c, f.param);
+            switch (f.field) {
+                case FusedBuilder::F_GAMMA: o.gamma = p; break;
+                case FusedBuilder::F_BETA: o.beta = p; break;
+                case FusedBuilder::F_BIAS: case FusedBuilder::F_BIAS_ARENA: o.bias = p; break;
+                case FusedBuilder::F_BIAS2: o.bias2 = p; break;
+                case FusedBuilder::F_W: o.main_ph.w = p; break;
+                case FusedBuilder::F_SC0W: o.sc[0].w = p; break;
+                case FusedBuilder::F_SC1W: o.sc[1].w = p; break;
+            }
+        }
+        HIP_OK(hipMemcpyAsync(c->d_fprog, c->fprog.data(), c->fprog.size() * sizeof(FOp), hipMemcpyHostToDevice, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
     c->packed_valid = true;
     return 0;
 }
@@ -713,6 +1138,7 @@ struct FwdIn {
 int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     const rdmi_arch& a = c->arch;
     if (f.NB < 1 || f.NB > c->max_batch) return fail("batch %d outside [1, %d] (rdmi_create max_batch)", f.NB, c->max_batch);
+    if (a.scale_by_sigma) return fail("scale_by_sigma=True is not built (all shipped NCSN++ configs set it False, RD/configs/model/ncsnpp.yaml)");
     if (a.conditional && !f.labels) return fail("class_labels is required: the model is conditional (label_emb) -- reference raises here too (RD/models/ncsnpp.py:262)");
     const int T = c->temb, Np_t = (T + 63) & ~63, Np_d = (c->dense_total + 63) & ~63;
     // ---- embedding: Fourier -> Linear -> SiLU -> Linear (+label_emb) -> [SiLU -> all Dense_0]
@@ -741,7 +1167,20 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
         hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_d / 64)), dim3(RDMI_THREADS), 0, s, l3);
     }
     HIP_OK(hipGetLastError());
-    // ---- the U-Net
+    // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
+    if (c->fused_ok && c->use_fused && !c->debug_taps) {
+        static bool attr_set = false;
+        if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        UnetArgs ua = c->fargs;
+        ua.x_in = f.x; ua.x_mod = f.x_mod; ua.out = f.out; ua.NB = f.NB;
+        double fl = 0;
+        for (auto& op : c->ops) fl += op.flops_per_sample;
+        ProfScope ps(c, s, "unet_wg_kernel", fl * f.NB);
+        hipLaunchKernelGGL(unet_wg_kernel, dim3((unsigned)f.NB), dim3(UW_THREADS), c->fused_lds, s, ua);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    // ---- ... or the layer-by-layer plan (debug taps, shapes the fused planner cannot fit in LDS)
     for (auto& op : c->ops) {
         if (op.kind == OP_CONV) {
             ConvArgs ca = op.conv;
@@ -757,7 +1196,6 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
             if (int e = launch_attn(aa, s)) return e;
         }
     }
-    if (a.scale_by_sigma) return fail("scale_by_sigma=True is not built (all shipped NCSN++ configs set it False, RD/configs/model/ncsnpp.yaml)");
     return 0;
 }
 
@@ -769,6 +1207,14 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
 extern "C" {
 
 const char* rdmi_last_error(void) { return g_err.c_str(); }
+const char* rdmi_path_info(rdmi_ctx* c) {
+    static thread_local std::string s;
+    if (!c) return "";
+    s = (c->fused_ok && c->use_fused && !c->debug_taps) ? "fused: workgroup-resident U-Net, " + std::to_string(c->fprog.size()) + " ops, " + std::to_string(c->fused_lds) + " B LDS"
+                                                        : "layers: " + std::to_string(c->ops.size()) + " launches" + (c->fused_ok ? "" : " (fused unavailable: " + c->fused_why + ")");
+    return s.c_str();
+}
+
 const char* rdmi_version(void) {
 #ifdef RDMI_EMU
     return "rdmi 0.1 (CPU execution-model emulator build: tests only)";
@@ -787,6 +1233,7 @@ int rdmi_create(const rdmi_arch* arch, int max_batch, int H, int W, rdmi_ctx** o
     c->max_batch = max_batch; c->H = H; c->W = W;
     c->temb = arch->nf * 4;
     if (const char* e = std::getenv("RDMI_DEBUG_TAPS")) c->debug_taps = atoi(e) != 0;
+    if (const char* e = std::getenv("RDMI_PATH")) c->use_fused = std::string(e) != "layers";
     int e = 0;
     try { e = build_plan(c); } catch (const std::exception& ex) { e = fail("plan construction failed: %s", ex.what()); }
     if (e) { rdmi_destroy(c); return e; }
@@ -796,7 +1243,7 @@ int rdmi_create(const rdmi_arch* arch, int max_batch, int H, int W, rdmi_ctx** o
 
 int rdmi_destroy(rdmi_ctx* c) {
     if (!c) return 0;
-    void* ptrs[] = {c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state};
+    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete c;

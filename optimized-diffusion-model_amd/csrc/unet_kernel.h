@@ -1,0 +1,416 @@
+// Workgroup-resident U-Net: ONE launch runs NCSNpp.forward (RD/models/ncsnpp.py:226-354) for every sample,
+// one 512-thread workgroup (8 waves, 2 per SIMD) per sample, with every activation of that sample held in
+// the CU's 160 KiB LDS.  Only weights stream in (from L2 / Infinity Cache: 25 MB shared by all workgroups,
+// each workgroup reads them once per forward) and only the skip tensors that do not fit round-trip through
+// the workgroup's own slice of a global scratch buffer.  This is the MI355X-first shape of the path:
+//   * 256 samples (B=128 with classifier-free guidance) == 256 CUs: no tail, no inter-workgroup dependency,
+//     so the ~57 kernel boundaries (~5 us each) and per-layer prologues of a layer-by-layer plan disappear;
+//   * GroupNorm statistics, SiLU, concat/resize gathers, residuals and the whole 81x81 attention stay in LDS;
+//   * all contractions (3x3 convs as 9 row-offset views, NIN, attention, output head) run on the exact-fp32
+//     MFMA v_mfma_f32_16x16x4_f32, B operands prefetched through a register ring.
+// The kernel is an interpreter of a small host-built op list (csrc/rdmi.hip: build_fused_program), so any
+// (ch_mult, num_res_blocks, H, W) the planner can fit in LDS runs without new device code.
+#pragma once
+#include "common.h"
+
+#define UW_THREADS 512
+#define UW_WAVES 8
+
+enum { FOP_GATHER = 0, FOP_STORE = 1, FOP_GN = 2, FOP_CONV = 3, FOP_ATTN = 4 };
+
+struct FPhase {            // one K-phase of a contraction: A rows come from an LDS tensor through a row table
+    int lds_off;           // byte offset of the A tensor in LDS
+    int rs;                // its row stride in floats
+    int nch;               // 16-channel chunks in this phase
+    int tab_off;           // byte offset in LDS of this phase's int16 row table [Mpad] (-1 entries = zero row)
+    const float* w;        // packed weights [nch][Cout_pad][16] for this phase
+};
+
+struct FOp {
+    int kind;
+    // ---- GATHER: dst[row][0:CA+CB] = concat(A[map(row)], B[row]); sources in LDS or global ([n][rows][C])
+    // ---- STORE : global[n][rows][C] = LDS tensor
+    // ---- GN    : in-place GroupNorm (+SiLU when act) of an LDS tensor
+    // ---- CONV  : dst = scale * (sum_phases A_phase . W_phase + bias [+bias2] [+dense[n]] [+resid])
+    // ---- ATTN  : O = softmax(Q K^T * scale) V for LDS-resident Q, K, Vt
+    int dst_off, dst_rs, rows, C;                 // generic destination / tensor description
+    int CA, CB;                                   // GATHER
+    int a_off, a_rs, a_hw, a_mod, a_map_off;      // GATHER source A: a_off < 0 -> global a_g ([n % a_mod][a_hw][CA])
+    int b_off, b_rs;                              // GATHER source B: b_off < 0 -> global b_g ([n][rows][CB])
+    const float* a_g; const float* b_g;
+    float* g_out;                                 // STORE / CONV(dst_kind 2) global destination
+    int G, act; float eps;                        // GN
+    const float* gamma; const float* beta;
+    int ntap; int tab_off[9];                     // CONV main phases (taps) share lds/rs/nch, weights contiguous
+    FPhase main_ph;                               //   (tab_off of main_ph unused; per-tap tables in tab_off[])
+    int nsc; FPhase sc[2];                        // CONV extra phases (NIN shortcut over raw sources)
+    int mtiles, Cout, Cout_pad;
+    const float* bias; const float* bias2;
+    int dense_off;                                // >= 0: add dense[n][dense_off + col]
+    int resid_off, resid_rs;                      // >= 0: add LDS tensor [row][col]
+    float scale;
+    int dst_kind;                                 // 0: LDS [row][col]; 1: LDS transposed [col][row]; 2: global [n][row][col]
+    int q_off, k_off, vt_off, p_off, qk_rs, ps;   // ATTN
+    int L, Lpad; float att_scale;
+};
+
+struct UnetArgs {
+    const FOp* prog; int nops;
+    const short* tabs; int tab_bytes;             // all row tables, copied to LDS offset tab_base at start
+    int tab_base;                                 // LDS byte offset of the table region
+    int zero_off;                                 // LDS byte offset of a zero row (>= max row bytes)
+    int zero_bytes;
+    const float* dense; int dense_stride;         // [n][dense_stride] Dense_0 outputs of the embedding kernels
+    const float* x_in; int x_mod;                 // network input [x_mod or NB][HW][channels] (GATHER with a_off == -2)
+    float* out;                                   // network output [NB][HW][channels]   (CONV dst_kind 2, g_out null)
+    int NB;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float* lds_f(int off) { return reinterpret_cast<float*>(rdmi_lds + off); }
+
+__device__ __forceinline__ void fop_gather(const FOp& o, const UnetArgs& u, int n, int tid) {
+    const int Cd = o.C;                               // padded total channels (multiple of 4)
+    const int c4n = Cd >> 2;
+    const int total = o.rows * c4n;
+    float* dst = lds_f(o.dst_off);
+    const short* map = o.a_map_off >= 0 ? reinterpret_cast<const short*>(rdmi_lds + o.a_map_off) : nullptr;
+    const int dpv = UW_THREADS / c4n, dc4 = UW_THREADS - dpv * c4n;
+    int row = tid / c4n, c4 = tid - row * c4n;
+    const bool from_x = o.a_off == -2;
+    const float* ag = from_x ? u.x_in : o.a_g;
+    const int amod = from_x ? u.x_mod : o.a_mod;
+    const int nA = amod > 0 ? n % amod : n;
+    for (int i = tid; i < total; i += UW_THREADS) {
+        const int c = c4 << 2;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (c < o.CA) {
+            const int srow = map ? map[row] : row;
+            if (o.a_off >= 0) {
+                val = *reinterpret_cast<const f32x4*>(lds_f(o.a_off) + (size_t)srow * o.a_rs + c);
+            } else {
+                const float* p = ag + ((size_t)nA * o.a_hw + srow) * o.CA + c;
+                if ((o.CA & 3) == 0) val = *reinterpret_cast<const f32x4*>(p);
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < o.CA) val[j] = p[j];
+            }
+        } else if (c < o.CA + o.CB) {
+            if (o.b_off >= 0) val = *reinterpret_cast<const f32x4*>(lds_f(o.b_off) + (size_t)row * o.b_rs + (c - o.CA));
+            else val = *reinterpret_cast<const f32x4*>(o.b_g + ((size_t)n * o.rows + row) * o.CB + (c - o.CA));
+        }
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * o.dst_rs + c) = val;
+        row += dpv; c4 += dc4;
+        if (c4 >= c4n) { c4 -= c4n; ++row; }
+    }
+}
+
+__device__ __forceinline__ void fop_store(const FOp& o, int n, int tid) {
+    const int c4n = o.C >> 2;
+    const int total = o.rows * c4n;
+    const float* src = lds_f(o.dst_off);
+    float* g = o.g_out + (size_t)n * o.rows * o.C;
+    const int dpv = UW_THREADS / c4n, dc4 = UW_THREADS - dpv * c4n;
+    int row = tid / c4n, c4 = tid - row * c4n;
+    for (int i = tid; i < total; i += UW_THREADS) {
+        *reinterpret_cast<f32x4*>(g + (size_t)row * o.C + (c4 << 2)) = *reinterpret_cast<const f32x4*>(src + (size_t)row * o.dst_rs + (c4 << 2));
+        row += dpv; c4 += dc4;
+        if (c4 >= c4n) { c4 -= c4n; ++row; }
+    }
+}
+
+// In-place GroupNorm (two-pass statistics, T lanes per group) + affine (+ SiLU).  stat: LDS scratch [2*G].
+__device__ __forceinline__ void fop_gn(const FOp& o, float* stat, int tid) {
+    float* X = lds_f(o.dst_off);
+    const int G = o.G, Cg = o.C / G, rs = o.dst_rs;
+    const int T = UW_THREADS / G;                     // 16 or 32 lanes per group (host-checked power of two <= 64)
+    const int g = tid / T, sub = tid - g * T;
+    const float inv_cnt = 1.0f / (float)(Cg * o.rows);
+    const float* base = X + g * Cg;
+    float sum = 0.f;
+    for (int v = sub; v < o.rows; v += T)
+        for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * rs + cc];
+    for (int m = T >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    const float mean = sum * inv_cnt;
+    float sq = 0.f;
+    for (int v = sub; v < o.rows; v += T)
+        for (int cc = 0; cc < Cg; ++cc) {
+            const float d = base[(size_t)v * rs + cc] - mean;
+            sq += d * d;
+        }
+    for (int m = T >> 1; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o.eps); }
+    __syncthreads();
+    const int c4n = o.C >> 2;
+    const int total = o.rows * c4n;
+    const int dpv = UW_THREADS / c4n, dc4 = UW_THREADS - dpv * c4n;
+    int row = tid / c4n, c4 = tid - row * c4n;
+    for (int i = tid; i < total; i += UW_THREADS) {
+        const int c = c4 << 2;
+        float* p = X + (size_t)row * rs + c;
+        f32x4 val = *reinterpret_cast<f32x4*>(p);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(o.gamma + c), bt = *reinterpret_cast<const f32x4*>(o.beta + c);
+        int gg = c / Cg, left = Cg - (c - gg * Cg);
+        for (int j = 0; j < 4; ++j) {
+            if (left == 0) { ++gg; left = Cg; }
+            const float y = (val[j] - stat[2 * gg]) * stat[2 * gg + 1] * gm[j] + bt[j];
+            val[j] = o.act ? silu_f(y) : y;
+            --left;
+        }
+        *reinterpret_cast<f32x4*>(p) = val;
+        row += dpv; c4 += dc4;
+        if (c4 >= c4n) { c4 -= c4n; ++row; }
+    }
+}
+
+// A-row byte offset for one table entry (-1 -> the shared zero row)
+__device__ __forceinline__ int arow(const short* tab, int m, int lds_off, int rs, int zero_off) {
+    const int r = tab[m];
+    return r < 0 ? zero_off : lds_off + r * rs * 4;
+}
+
+// One wave's share of a CONV op: NMT row tiles x one column tile; weights through a PF-deep register ring.
+template <int NMT, int PF>
+__device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int n, int wm, int WM, int nt, int lane) {
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int col = nt * 16 + lrow;
+    f32x4 acc[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int mrow[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) mrow[i] = (wm + i * WM) * 16 + lrow;
+
+    // ---- main phases (taps): flattened step q = tap * nch + chunk
+    {
+        const int nch = o.main_ph.nch, nsteps = o.ntap * nch;
+        const size_t bstride = (size_t)o.Cout_pad * 16;
+        const float* Wl = o.main_ph.w + (size_t)col * 16 + kq * 4;
+        f32x4 ring[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (p < nsteps) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)p * bstride);
+        int ph = 0, ch = 0;
+        int abase[NMT];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i)
+            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[0]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
+        for (int q = 0; q < nsteps; q += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int qq = q + p;
+                if (qq < nsteps) {
+                    f32x4 af[NMT];
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                    if (qq + PF < nsteps) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(qq + PF) * bstride);
+                    if (++ch == nch) {
+                        ch = 0; ++ph;
+                        if (ph < o.ntap) {
+#pragma unroll
+                            for (int i = 0; i < NMT; ++i)
+                                abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[ph]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- shortcut phases (raw block input through NIN_0)
+    for (int s = 0; s < o.nsc; ++s) {
+        const FPhase& ph = o.sc[s];
+        const size_t bstride = (size_t)o.Cout_pad * 16;
+        const float* Wl = ph.w + (size_t)col * 16 + kq * 4;
+        int abase[NMT];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i)
+            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + ph.tab_off), mrow[i], ph.lds_off, ph.rs, u.zero_off) + kq * 16;
+        f32x4 ring[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (p < ph.nch) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)p * bstride);
+        for (int q = 0; q < ph.nch; q += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int qq = q + p;
+                if (qq < ph.nch) {
+                    f32x4 af[NMT];
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + qq * 64);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                    if (qq + PF < ph.nch) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(qq + PF) * bstride);
+                }
+            }
+        }
+    }
+    // ---- epilogue
+    if (col < o.Cout || o.dst_kind == 1) {
+        float add = col < o.Cout ? o.bias[col] : 0.f;
+        if (o.bias2 && col < o.Cout) add += o.bias2[col];
+        if (o.dense_off >= 0) add += u.dense[(size_t)n * u.dense_stride + o.dense_off + col];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+            const int row0 = (wm + i * WM) * 16 + kq * 4;
+            if (o.dst_kind == 1) {                    // transposed [col][row], all padded rows written (finite)
+                f32x4 v = acc[i];
+                for (int r = 0; r < 4; ++r) v[r] = (v[r] + add) * o.scale;
+                *reinterpret_cast<f32x4*>(lds_f(o.dst_off) + (size_t)col * o.dst_rs + row0) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + r;
+                    if (row >= o.rows) continue;
+                    float v = acc[i][r] + add;
+                    if (o.resid_off >= 0) v += lds_f(o.resid_off)[(size_t)row * o.resid_rs + col];
+                    v *= o.scale;
+                    if (o.dst_kind == 0) lds_f(o.dst_off)[(size_t)row * o.dst_rs + col] = v;
+                    else (o.g_out ? o.g_out : u.out)[((size_t)n * o.rows + row) * o.Cout + col] = v;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void fop_conv(const FOp& o, const UnetArgs& u, int n, int wave, int lane) {
+    const int ntiles = o.Cout_pad >> 4;
+    const int WN = ntiles >= 8 ? 8 : (ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1));
+    const int WM = UW_WAVES / WN;
+    const int wn = wave % WN, wm = wave / WN;
+    const int nmt = o.mtiles > wm ? (o.mtiles - wm + WM - 1) / WM : 0;
+    for (int nt = wn; nt < ntiles; nt += WN) {
+        switch (nmt) {
+            case 1: fconv_wave<1, 8>(o, u, n, wm, WM, nt, lane); break;
+            case 2: fconv_wave<2, 4>(o, u, n, wm, WM, nt, lane); break;
+            case 3: fconv_wave<3, 3>(o, u, n, wm, WM, nt, lane); break;
+            case 4: fconv_wave<4, 2>(o, u, n, wm, WM, nt, lane); break;
+            case 5: fconv_wave<5, 2>(o, u, n, wm, WM, nt, lane); break;
+            case 6: fconv_wave<6, 2>(o, u, n, wm, WM, nt, lane); break;
+            default: break;
+        }
+    }
+}
+
+// Attention core on LDS tensors: P = softmax(Q K^T * scale) (rows = queries), O = P V.
+// Q, K: [L][qk_rs]; Vt: [C][ps] (keys along the row, all Lpad columns finite); P: [L][ps]; O -> dst [L][dst_rs].
+// C = 64 channels (one 16-wide channel tile per wave pair).
+__device__ __forceinline__ void fop_attn(const FOp& o, int wave, int lane) {
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int L = o.L, mtiles = o.Lpad >> 4;
+    const float* Q = lds_f(o.q_off);
+    const float* K = lds_f(o.k_off);
+    const float* Vt = lds_f(o.vt_off);
+    float* P = lds_f(o.p_off);
+    const int rs = o.qk_rs, ps = o.ps;
+    const int nchq = o.C >> 4;
+    // ---- scores + softmax: wave w owns query tile w (tiles >= 8 loop)
+    for (int mt = wave; mt < mtiles; mt += UW_WAVES) {
+        f32x4 s[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int qrow = min(mt * 16 + lrow, L - 1);
+        for (int ch = 0; ch < nchq; ++ch) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(Q + (size_t)qrow * rs + ch * 16 + kq * 4);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                if (t < mtiles) {
+                    const int krow = min(t * 16 + lrow, L - 1);
+                    const f32x4 bf = *reinterpret_cast<const f32x4*>(K + (size_t)krow * rs + ch * 16 + kq * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[t] = mfma16(af[j], bf[j], s[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if (t < mtiles && t * 16 + lrow < L) { s[t][r] *= o.att_scale; mx = fmaxf(mx, s[t][r]); }
+            for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if (t < mtiles) {
+                    const float e = (t * 16 + lrow < L) ? __expf(s[t][r] - mx) : 0.f;
+                    s[t][r] = e;
+                    sum += e;
+                }
+            for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+            const float inv = 1.0f / sum;
+            const int row = mt * 16 + kq * 4 + r;
+            if (row < L) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    if (t < mtiles) P[(size_t)row * ps + t * 16 + lrow] = s[t][r] * inv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- O = P V: 4 channel tiles x mtiles row tiles over 8 waves (wave = (row half, channel tile))
+    {
+        const int wn = wave & 3, wm = wave >> 2;
+        const int col = wn * 16 + lrow;
+        f32x4 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < mtiles; ++ch) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(Vt + (size_t)col * ps + ch * 16 + kq * 4);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int mt = wm + 2 * i;
+                if (mt < mtiles) {
+                    const int prow = min(mt * 16 + lrow, L - 1);
+                    const f32x4 af = *reinterpret_cast<const f32x4*>(P + (size_t)prow * ps + ch * 16 + kq * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i] = mfma16(af[j], bf[j], acc[i]);
+                }
+            }
+        }
+        float* O = lds_f(o.dst_off);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int mt = wm + 2 * i;
+            if (mt < mtiles)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + kq * 4 + r;
+                    if (row < L) O[(size_t)row * o.dst_rs + col] = acc[i][r];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x;
+    // tables + zero row
+    {
+        const int nw = u.tab_bytes >> 2;
+        const int* src = reinterpret_cast<const int*>(u.tabs);
+        int* dst = reinterpret_cast<int*>(rdmi_lds + u.tab_base);
+        for (int i = tid; i < nw; i += UW_THREADS) dst[i] = src[i];
+        float* z = lds_f(u.zero_off);
+        for (int i = tid; i < (u.zero_bytes >> 2); i += UW_THREADS) z[i] = 0.f;
+    }
+    float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
+    __syncthreads();
+    for (int pc = 0; pc < u.nops; ++pc) {
+        const FOp& o = u.prog[pc];
+        switch (o.kind) {
+            case FOP_GATHER: fop_gather(o, u, n, tid); break;
+            case FOP_STORE: fop_store(o, n, tid); break;
+            case FOP_GN: fop_gn(o, stat, tid); break;
+            case FOP_CONV: fop_conv(o, u, n, wave, lane); break;
+            case FOP_ATTN: fop_attn(o, wave, lane); break;
+            default: break;
+        }
+        __syncthreads();
+    }
+}

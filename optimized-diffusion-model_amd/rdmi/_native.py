@@ -53,6 +53,7 @@ _PROTOS = {
     'rdmi_set_profiling': ([C.c_void_p, C.c_int], C.c_int),
     'rdmi_get_profile': ([C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long),
                           C.POINTER(C.c_double)], C.c_int),
+    'rdmi_path_info': ([C.c_void_p], C.c_char_p),
     'rdmi_last_error': ([], C.c_char_p),
     'rdmi_version': ([], C.c_char_p),
 }
@@ -182,6 +183,9 @@ class Context:
                                      stream_of(like)))
         n = c.value * h.value * w.value
         return buf[:nb * n].reshape(nb, c.value, h.value, w.value).clone()
+
+    def path_info(self):
+        return lib().rdmi_path_info(self._h).decode()
 
     def set_profiling(self, on):
         check(lib().rdmi_set_profiling(self._h, int(bool(on))))
