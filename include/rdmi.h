@@ -144,6 +144,10 @@ int rdmi_get_profile(rdmi_ctx* ctx, int index, const char** kernel_name, double*
 /* Which execution plan the context uses ("fused: ..." or "layers: ... (reason)"). */
 const char* rdmi_path_info(rdmi_ctx* ctx);
 
+/* Diagnostic (RDMI_STAMPS=1 at create): shader-clock cycles workgroup 0 spent in each op of the fused program
+ * during the last forward, with a one-line description per op.  Returns the op count. */
+int rdmi_debug_op_cycles(rdmi_ctx* ctx, long long* host_cycles, int cap, const char** desc, int desc_cap);
+
 const char* rdmi_last_error(void);
 const char* rdmi_version(void);
 

@@ -26,3 +26,24 @@ __device__ __forceinline__ float reflect_f(float x) {
     m = (m >= 2.0f) ? 0.0f : m;
     return (m > 1.0f) ? 2.0f - m : m;
 }
+
+// 16-byte load through the GLOBAL address space.  Pointers that the kernel reads out of memory (op lists) are
+// "generic" to the compiler, which then emits flat_load: flat loads also count on lgkmcnt, so every LDS wait
+// would drain the whole weight-prefetch ring.  The device pass casts to address space 1 (global_load_dwordx4);
+// host-side passes (which never execute this) see a plain load.
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const f32x4 __attribute__((address_space(1))) * gptr_t;
+    return *(gptr_t)(p);
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ float ldg1(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const float __attribute__((address_space(1))) * gptr_t;
+    return *(gptr_t)(p);
+#else
+    return *p;
+#endif
+}

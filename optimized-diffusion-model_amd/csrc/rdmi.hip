@@ -119,6 +119,8 @@ struct rdmi_ctx {
     FOp* d_fprog = nullptr; short* d_ftabs = nullptr;
     float* d_spill = nullptr; size_t spill_per_sample = 0;
     UnetArgs fargs{};
+    long long* d_stamps = nullptr;       // diagnostic (RDMI_STAMPS=1)
+    std::vector<std::string> fdesc;      // one line per fused op
     size_t fused_lds = 0;
     std::map<std::string, size_t> wmap;  // packed-weight arena offsets by parameter prefix
     bool packed_valid = false;
@@ -910,7 +912,7 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     }
     // LDS: [row tables] [zero row] [GN stats] [tensor arena]
     const int zero_bytes = 1280;                     // >= (Cmax/16)*64 + 64 for Cmax = 256... host-checked below
-    const int stat_bytes = 256;
+    const int stat_bytes = 256 + 2 * (int)sizeof(FOp) + 64;   // GN scratch + two staged op descriptors
     b.arena_init(TAB_RESERVE + zero_bytes + stat_bytes);
     int H = c->H, W = c->W;
     if (H * W > 96) { c->fused_why = "more than 96 pixels per sample"; return 0; }
@@ -1005,6 +1007,15 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     c->fargs.zero_off = TAB_RESERVE; c->fargs.zero_bytes = zero_bytes;
     c->fargs.dense = c->d_dense; c->fargs.dense_stride = c->dense_total;
     c->fused_lds = (size_t)b.high_water;
+    if (std::getenv("RDMI_STAMPS")) { HIP_OK(hipMalloc((void**)&c->d_stamps, (c->fprog.size() + 1) * sizeof(long long))); c->fargs.stamps = c->d_stamps; }
+    c->fdesc.clear();
+    for (auto& o : c->fprog) {
+        char buf[160];
+        const char* kn[] = {"GATHER", "STORE", "GN", "CONV", "ATTN"};
+        if (o.kind == FOP_CONV) snprintf(buf, sizeof buf, "CONV rows=%d mtiles=%d K=%dx%d(+%d) Cout=%d dst=%d", o.rows, o.mtiles, o.ntap, o.main_ph.nch * 16, o.nsc ? o.sc[0].nch * 16 : 0, o.Cout, o.dst_kind);
+        else snprintf(buf, sizeof buf, "%s rows=%d C=%d", kn[o.kind], o.rows, o.C);
+        c->fdesc.push_back(buf);
+    }
     c->fused_ok = true;
     return 0;
 }
@@ -1207,6 +1218,16 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
 extern "C" {
 
 const char* rdmi_last_error(void) { return g_err.c_str(); }
+int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** desc, int desc_cap) {
+    if (!c || !c->d_stamps) return 0;
+    const int n = (int)c->fprog.size();
+    std::vector<long long> st((size_t)n + 1);
+    if (hipMemcpy(st.data(), c->d_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (int i = 0; i < n && i < cap; ++i) host[i] = st[(size_t)i + 1] - st[(size_t)i];
+    for (int i = 0; i < n && i < desc_cap; ++i) desc[i] = c->fdesc[(size_t)i].c_str();
+    return n;
+}
+
 const char* rdmi_path_info(rdmi_ctx* c) {
     static thread_local std::string s;
     if (!c) return "";

@@ -64,6 +64,7 @@ struct UnetArgs {
     const float* x_in; int x_mod;                 // network input [x_mod or NB][HW][channels] (GATHER with a_off == -2)
     float* out;                                   // network output [NB][HW][channels]   (CONV dst_kind 2, g_out null)
     int NB;
+    long long* stamps;                            // diagnostic: per-op shader-clock stamps of workgroup 0 (null in production)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -90,14 +91,14 @@ __device__ __forceinline__ void fop_gather(const FOp& o, const UnetArgs& u, int 
                 val = *reinterpret_cast<const f32x4*>(lds_f(o.a_off) + (size_t)srow * o.a_rs + c);
             } else {
                 const float* p = ag + ((size_t)nA * o.a_hw + srow) * o.CA + c;
-                if ((o.CA & 3) == 0) val = *reinterpret_cast<const f32x4*>(p);
+                if ((o.CA & 3) == 0) val = ldg4(p);
                 else
                     for (int j = 0; j < 4; ++j)
                         if (c + j < o.CA) val[j] = p[j];
             }
         } else if (c < o.CA + o.CB) {
             if (o.b_off >= 0) val = *reinterpret_cast<const f32x4*>(lds_f(o.b_off) + (size_t)row * o.b_rs + (c - o.CA));
-            else val = *reinterpret_cast<const f32x4*>(o.b_g + ((size_t)n * o.rows + row) * o.CB + (c - o.CA));
+            else val = ldg4(o.b_g + ((size_t)n * o.rows + row) * o.CB + (c - o.CA));
         }
         *reinterpret_cast<f32x4*>(dst + (size_t)row * o.dst_rs + c) = val;
         row += dpv; c4 += dc4;
@@ -120,6 +121,7 @@ __device__ __forceinline__ void fop_store(const FOp& o, int n, int tid) {
 }
 
 // In-place GroupNorm (two-pass statistics, T lanes per group) + affine (+ SiLU).  stat: LDS scratch [2*G].
+// Work-items keep a FIXED float4 channel column (gamma/beta/group loaded once, before the row loop).
 __device__ __forceinline__ void fop_gn(const FOp& o, float* stat, int tid) {
     float* X = lds_f(o.dst_off);
     const int G = o.G, Cg = o.C / G, rs = o.dst_rs;
@@ -128,38 +130,55 @@ __device__ __forceinline__ void fop_gn(const FOp& o, float* stat, int tid) {
     const float inv_cnt = 1.0f / (float)(Cg * o.rows);
     const float* base = X + g * Cg;
     float sum = 0.f;
-    for (int v = sub; v < o.rows; v += T)
-        for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * rs + cc];
+    if ((Cg & 3) == 0) {
+        for (int v = sub; v < o.rows; v += T)
+            for (int cc = 0; cc < Cg; cc += 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * rs + cc);
+                sum += (q[0] + q[1]) + (q[2] + q[3]);
+            }
+    } else {
+        for (int v = sub; v < o.rows; v += T)
+            for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * rs + cc];
+    }
     for (int m = T >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
     const float mean = sum * inv_cnt;
     float sq = 0.f;
-    for (int v = sub; v < o.rows; v += T)
-        for (int cc = 0; cc < Cg; ++cc) {
-            const float d = base[(size_t)v * rs + cc] - mean;
-            sq += d * d;
-        }
+    if ((Cg & 3) == 0) {
+        for (int v = sub; v < o.rows; v += T)
+            for (int cc = 0; cc < Cg; cc += 4) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * rs + cc);
+                const float d0 = q[0] - mean, d1 = q[1] - mean, d2 = q[2] - mean, d3 = q[3] - mean;
+                sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+    } else {
+        for (int v = sub; v < o.rows; v += T)
+            for (int cc = 0; cc < Cg; ++cc) {
+                const float d = base[(size_t)v * rs + cc] - mean;
+                sq += d * d;
+            }
+    }
     for (int m = T >> 1; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
     if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o.eps); }
-    __syncthreads();
+    // fixed channel quad per work-item: rows advance by rstep; work-items beyond rstep*c4n idle (C = 192)
     const int c4n = o.C >> 2;
-    const int total = o.rows * c4n;
-    const int dpv = UW_THREADS / c4n, dc4 = UW_THREADS - dpv * c4n;
-    int row = tid / c4n, c4 = tid - row * c4n;
-    for (int i = tid; i < total; i += UW_THREADS) {
-        const int c = c4 << 2;
-        float* p = X + (size_t)row * rs + c;
-        f32x4 val = *reinterpret_cast<f32x4*>(p);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(o.gamma + c), bt = *reinterpret_cast<const f32x4*>(o.beta + c);
-        int gg = c / Cg, left = Cg - (c - gg * Cg);
-        for (int j = 0; j < 4; ++j) {
-            if (left == 0) { ++gg; left = Cg; }
-            const float y = (val[j] - stat[2 * gg]) * stat[2 * gg + 1] * gm[j] + bt[j];
-            val[j] = o.act ? silu_f(y) : y;
-            --left;
+    const int rstep = UW_THREADS / c4n;
+    const int r0 = tid / c4n, c = (tid - r0 * c4n) << 2;
+    const bool active = r0 < rstep;
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+    if (active) { gm = ldg4(o.gamma + c); bt = ldg4(o.beta + c); }
+    __syncthreads();
+    if (active) {
+        f32x4 mu, rstd;
+        for (int j = 0; j < 4; ++j) { const int gg = (c + j) / Cg; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * gm[j]; }
+        for (int row = r0; row < o.rows; row += rstep) {
+            float* p = X + (size_t)row * rs + c;
+            f32x4 val = *reinterpret_cast<f32x4*>(p);
+            for (int j = 0; j < 4; ++j) {
+                const float y = (val[j] - mu[j]) * rstd[j] + bt[j];
+                val[j] = o.act ? silu_f(y) : y;
+            }
+            *reinterpret_cast<f32x4*>(p) = val;
         }
-        *reinterpret_cast<f32x4*>(p) = val;
-        row += dpv; c4 += dc4;
-        if (c4 >= c4n) { c4 -= c4n; ++row; }
     }
 }
 
@@ -180,41 +199,67 @@ __device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int 
     int mrow[NMT];
 #pragma unroll
     for (int i = 0; i < NMT; ++i) mrow[i] = (wm + i * WM) * 16 + lrow;
+    // epilogue operands are fetched now so their global latency hides under the GEMM
+    float add = 0.f;
+    if (col < o.Cout) {
+        add = ldg1(o.bias + col);
+        if (o.bias2) add += ldg1(o.bias2 + col);
+        if (o.dense_off >= 0) add += ldg1(u.dense + (size_t)n * u.dense_stride + o.dense_off + col);
+    }
 
-    // ---- main phases (taps): flattened step q = tap * nch + chunk
+    // ---- main phases (taps): flattened step q = tap * nch + chunk.
+    // Ring refills are UNCONDITIONAL straight-line loads (index clamped at the end), so the compiler can count the
+    // outstanding loads and wait with vmcnt(PF-1) instead of draining the ring at every branch.
     {
         const int nch = o.main_ph.nch, nsteps = o.ntap * nch;
         const size_t bstride = (size_t)o.Cout_pad * 16;
         const float* Wl = o.main_ph.w + (size_t)col * 16 + kq * 4;
         f32x4 ring[PF];
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
-            if (p < nsteps) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)p * bstride);
+        for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nsteps - 1) * bstride);
         int ph = 0, ch = 0;
         int abase[NMT];
 #pragma unroll
         for (int i = 0; i < NMT; ++i)
             abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[0]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
-        for (int q = 0; q < nsteps; q += PF) {
+        const int nfull = (nsteps / PF) * PF;
+        for (int q = 0; q < nfull; q += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
-                const int qq = q + p;
-                if (qq < nsteps) {
-                    f32x4 af[NMT];
+                f32x4 af[NMT];
 #pragma unroll
-                    for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
-                    if (qq + PF < nsteps) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(qq + PF) * bstride);
-                    if (++ch == nch) {
-                        ch = 0; ++ph;
-                        if (ph < o.ntap) {
+                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nsteps - 1) * bstride);
+                if (++ch == nch) {
+                    ch = 0; ++ph;
+                    if (ph < o.ntap) {
 #pragma unroll
-                            for (int i = 0; i < NMT; ++i)
-                                abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[ph]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
-                        }
+                        for (int i = 0; i < NMT; ++i)
+                            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[ph]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (nfull + p < nsteps) {
+                f32x4 af[NMT];
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                if (++ch == nch) {
+                    ch = 0; ++ph;
+                    if (ph < o.ntap) {
+#pragma unroll
+                        for (int i = 0; i < NMT; ++i)
+                            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[ph]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
                     }
                 }
             }
@@ -223,6 +268,7 @@ __device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int 
     // ---- shortcut phases (raw block input through NIN_0)
     for (int s = 0; s < o.nsc; ++s) {
         const FPhase& ph = o.sc[s];
+        const int nch = ph.nch;
         const size_t bstride = (size_t)o.Cout_pad * 16;
         const float* Wl = ph.w + (size_t)col * 16 + kq * 4;
         int abase[NMT];
@@ -231,30 +277,36 @@ __device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int 
             abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + ph.tab_off), mrow[i], ph.lds_off, ph.rs, u.zero_off) + kq * 16;
         f32x4 ring[PF];
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
-            if (p < ph.nch) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)p * bstride);
-        for (int q = 0; q < ph.nch; q += PF) {
+        for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nch - 1) * bstride);
+        const int nfull = (nch / PF) * PF;
+        for (int q = 0; q < nfull; q += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
-                const int qq = q + p;
-                if (qq < ph.nch) {
-                    f32x4 af[NMT];
+                f32x4 af[NMT];
 #pragma unroll
-                    for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + qq * 64);
+                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + (q + p) * 64);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
-                    if (qq + PF < ph.nch) ring[p] = *reinterpret_cast<const f32x4*>(Wl + (size_t)(qq + PF) * bstride);
-                }
+                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nch - 1) * bstride);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (nfull + p < nch) {
+                f32x4 af[NMT];
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + (nfull + p) * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
             }
         }
     }
     // ---- epilogue
     if (col < o.Cout || o.dst_kind == 1) {
-        float add = col < o.Cout ? o.bias[col] : 0.f;
-        if (o.bias2 && col < o.Cout) add += o.bias2[col];
-        if (o.dense_off >= 0) add += u.dense[(size_t)n * u.dense_stride + o.dense_off + col];
 #pragma unroll
         for (int i = 0; i < NMT; ++i) {
             const int row0 = (wm + i * WM) * 16 + kq * 4;
@@ -279,19 +331,19 @@ __device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int 
 }
 
 __device__ __forceinline__ void fop_conv(const FOp& o, const UnetArgs& u, int n, int wave, int lane) {
-    const int ntiles = o.Cout_pad >> 4;
+    const int ntiles = __builtin_amdgcn_readfirstlane(o.Cout_pad >> 4);
     const int WN = ntiles >= 8 ? 8 : (ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1));
     const int WM = UW_WAVES / WN;
     const int wn = wave % WN, wm = wave / WN;
-    const int nmt = o.mtiles > wm ? (o.mtiles - wm + WM - 1) / WM : 0;
+    const int nmt = __builtin_amdgcn_readfirstlane(o.mtiles > wm ? (o.mtiles - wm + WM - 1) / WM : 0);
     for (int nt = wn; nt < ntiles; nt += WN) {
         switch (nmt) {
-            case 1: fconv_wave<1, 8>(o, u, n, wm, WM, nt, lane); break;
-            case 2: fconv_wave<2, 4>(o, u, n, wm, WM, nt, lane); break;
-            case 3: fconv_wave<3, 3>(o, u, n, wm, WM, nt, lane); break;
-            case 4: fconv_wave<4, 2>(o, u, n, wm, WM, nt, lane); break;
-            case 5: fconv_wave<5, 2>(o, u, n, wm, WM, nt, lane); break;
-            case 6: fconv_wave<6, 2>(o, u, n, wm, WM, nt, lane); break;
+            case 1: fconv_wave<1, 16>(o, u, n, wm, WM, nt, lane); break;
+            case 2: fconv_wave<2, 8>(o, u, n, wm, WM, nt, lane); break;
+            case 3: fconv_wave<3, 8>(o, u, n, wm, WM, nt, lane); break;
+            case 4: fconv_wave<4, 6>(o, u, n, wm, WM, nt, lane); break;
+            case 5: fconv_wave<5, 4>(o, u, n, wm, WM, nt, lane); break;
+            case 6: fconv_wave<6, 4>(o, u, n, wm, WM, nt, lane); break;
             default: break;
         }
     }
@@ -400,10 +452,18 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         for (int i = tid; i < (u.zero_bytes >> 2); i += UW_THREADS) z[i] = 0.f;
     }
     float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
+    // Op descriptors are staged in LDS, one op ahead (2 slots after the GN scratch): field reads inside the loops
+    // are then LDS reads (lgkmcnt) instead of global reads that would force vmcnt(0) under the weight ring.
+    constexpr int OPW = (int)(sizeof(FOp) / 4);
+    int* opslot = reinterpret_cast<int*>(stat + 64);
+    if (tid < OPW) opslot[tid] = reinterpret_cast<const int*>(u.prog)[tid];
     __syncthreads();
+    if (u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
     for (int pc = 0; pc < u.nops; ++pc) {
-        const FOp& o = u.prog[pc];
-        switch (o.kind) {
+        if (pc + 1 < u.nops && tid < OPW) opslot[((pc + 1) & 1) * OPW + tid] = reinterpret_cast<const int*>(u.prog + pc + 1)[tid];
+        const FOp& o = *reinterpret_cast<const FOp*>(opslot + (pc & 1) * OPW);
+        const int kind = __builtin_amdgcn_readfirstlane(o.kind);
+        switch (kind) {
             case FOP_GATHER: fop_gather(o, u, n, tid); break;
             case FOP_STORE: fop_store(o, n, tid); break;
             case FOP_GN: fop_gn(o, stat, tid); break;
@@ -412,5 +472,6 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
             default: break;
         }
         __syncthreads();
+        if (u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
     }
 }

@@ -54,6 +54,7 @@ _PROTOS = {
     'rdmi_get_profile': ([C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long),
                           C.POINTER(C.c_double)], C.c_int),
     'rdmi_path_info': ([C.c_void_p], C.c_char_p),
+    'rdmi_debug_op_cycles': ([C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_char_p), C.c_int], C.c_int),
     'rdmi_last_error': ([], C.c_char_p),
     'rdmi_version': ([], C.c_char_p),
 }
@@ -183,6 +184,12 @@ class Context:
                                      stream_of(like)))
         n = c.value * h.value * w.value
         return buf[:nb * n].reshape(nb, c.value, h.value, w.value).clone()
+
+    def op_cycles(self):
+        cyc = (C.c_longlong * 512)()
+        desc = (C.c_char_p * 512)()
+        n = lib().rdmi_debug_op_cycles(self._h, cyc, 512, desc, 512)
+        return [(desc[i].decode(), int(cyc[i])) for i in range(n)]
 
     def path_info(self):
         return lib().rdmi_path_info(self._h).decode()

@@ -82,6 +82,7 @@ inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_em
     return d;
 }
 
+inline long long clock64() { return 0; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
