@@ -47,3 +47,39 @@ __device__ __forceinline__ float ldg1(const float* p) {
     return *p;
 #endif
 }
+
+__device__ __forceinline__ void stg1(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float __attribute__((address_space(1))) * gptr_t;
+    *(gptr_t)(p) = v;
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void stg4(float* p, f32x4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef f32x4 __attribute__((address_space(1))) * gptr_t;
+    *(gptr_t)(p) = v;
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
+// Keep a value alive without using it (for L2-warming touches): the wait for the load lands where this is placed.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RDMI_KEEP(x) asm volatile("" ::"v"(x))
+#else
+#define RDMI_KEEP(x) ((void)(x))
+#endif
+
+// Wave-uniform values read out of LDS/global land in VGPRs; these pin them into scalar registers once, so later
+// uses are SGPR operands and (for values read from LDS) are not re-read after every LDS store.
+__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float sgpr_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <class T>
+__device__ __forceinline__ T* sgpr_p(T* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}

@@ -800,6 +800,7 @@ struct FusedBuilder {
         if (dst) { o.dst_off = dst->off; o.dst_rs = dst->rs; }
         if (resid) { o.resid_off = resid->off; o.resid_rs = resid->rs; }
         if (o.mtiles > 6) fail_("conv with more than 96 output pixels per sample");
+        if (sc_src) fail_("fused CONV ops carry no shortcut phases (the NIN shortcut is its own 1x1 op)");
         if (sc_src) {
             o.nsc = 1;
             o.sc[0].lds_off = sc_src->off; o.sc[0].rs = sc_src->rs; o.sc[0].nch = sc_src->C / 16; o.sc[0].tab_off = ident_table(Ho * Wo);
@@ -1007,7 +1008,8 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     c->fargs.zero_off = TAB_RESERVE; c->fargs.zero_bytes = zero_bytes;
     c->fargs.dense = c->d_dense; c->fargs.dense_stride = c->dense_total;
     c->fused_lds = (size_t)b.high_water;
-    if (std::getenv("RDMI_STAMPS")) { HIP_OK(hipMalloc((void**)&c->d_stamps, (c->fprog.size() + 1) * sizeof(long long))); c->fargs.stamps = c->d_stamps; }
+    if (const char* e = std::getenv("RDMI_UDBG")) c->fargs.dbg = atoi(e);
+    if (std::getenv("RDMI_STAMPS")) { HIP_OK(hipMalloc((void**)&c->d_stamps, (1024 + c->fprog.size() * 8 + 8) * sizeof(long long))); c->fargs.stamps = c->d_stamps; }
     c->fdesc.clear();
     for (auto& o : c->fprog) {
         char buf[160];
@@ -1222,8 +1224,16 @@ int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** des
     if (!c || !c->d_stamps) return 0;
     const int n = (int)c->fprog.size();
     std::vector<long long> st((size_t)n + 1);
+    if (n > 1000) return 0;
     if (hipMemcpy(st.data(), c->d_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     for (int i = 0; i < n && i < cap; ++i) host[i] = st[(size_t)i + 1] - st[(size_t)i];
+    // fine stamps of CONV ops (entry, ring issued, first B landed, main done, shortcut done, epilogue done) follow at cap/2
+    {
+        std::vector<long long> fs((size_t)n * 8);
+        if (hipMemcpy(fs.data(), c->d_stamps + 1024, fs.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < n && 256 + i * 6 + 5 < cap; ++i)
+                for (int k = 0; k < 6; ++k) host[256 + i * 6 + k] = fs[(size_t)i * 8 + k] - st[(size_t)i];
+    }
     for (int i = 0; i < n && i < desc_cap; ++i) desc[i] = c->fdesc[(size_t)i].c_str();
     return n;
 }

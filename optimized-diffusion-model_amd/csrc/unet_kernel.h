@@ -11,6 +11,8 @@
 // The kernel is an interpreter of a small host-built op list (csrc/rdmi.hip: build_fused_program), so any
 // (ch_mult, num_res_blocks, H, W) the planner can fit in LDS runs without new device code.
 #pragma once
+#include <cstddef>
+
 #include "common.h"
 
 #define UW_THREADS 512
@@ -64,13 +66,39 @@ struct UnetArgs {
     const float* x_in; int x_mod;                 // network input [x_mod or NB][HW][channels] (GATHER with a_off == -2)
     float* out;                                   // network output [NB][HW][channels]   (CONV dst_kind 2, g_out null)
     int NB;
+    int dbg;                                      // diagnostic ablations (0 in production): 1 = no ring refills, 2 = no MFMA
     long long* stamps;                            // diagnostic: per-op shader-clock stamps of workgroup 0 (null in production)
 };
 
 // ---------------------------------------------------------------------------------------------------------
+// Op descriptors live in REGISTERS: lane i of every wave holds 32-bit word i of the current FOp (two VGPRs cover
+// the struct), loaded straight from global one op ahead.  A field is one v_readlane into an SGPR: no LDS or global
+// latency on the op-transition path.
+struct OpW { int w0, w1; };
+static_assert(sizeof(FOp) <= 512, "FOp must fit two VGPRs per wave");
+__device__ __forceinline__ int opw_at(const OpW& r, int word) {
+    return word < 64 ? __builtin_amdgcn_readlane(r.w0, word) : __builtin_amdgcn_readlane(r.w1, word - 64);
+}
+#define OPI(r, field) opw_at(r, (int)(offsetof(FOp, field) / 4))
+#define OPF(r, field) __builtin_bit_cast(float, OPI(r, field))
+#define OPP(r, T, field) \
+    reinterpret_cast<T*>((unsigned long long)(unsigned)opw_at(r, (int)(offsetof(FOp, field) / 4)) | ((unsigned long long)(unsigned)opw_at(r, (int)(offsetof(FOp, field) / 4) + 1) << 32))
+__device__ __forceinline__ OpW opw_load(const FOp* op, int lane) {
+    OpW r;
+    constexpr int NW = (int)(sizeof(FOp) / 4);
+    const int* g = reinterpret_cast<const int*>(op);
+    r.w0 = lane < NW ? __builtin_bit_cast(int, ldg1(reinterpret_cast<const float*>(g + lane))) : 0;
+    r.w1 = lane + 64 < NW ? __builtin_bit_cast(int, ldg1(reinterpret_cast<const float*>(g + lane + 64))) : 0;
+    return r;
+}
+
 __device__ __forceinline__ float* lds_f(int off) { return reinterpret_cast<float*>(rdmi_lds + off); }
 
-__device__ __forceinline__ void fop_gather(const FOp& o, const UnetArgs& u, int n, int tid) {
+__device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int n, int tid) {
+    struct { int C, rows, dst_off, dst_rs, CA, CB, a_off, a_rs, a_hw, a_mod, a_map_off, b_off, b_rs; const float* a_g; const float* b_g; } o;
+    o.C = OPI(w, C); o.rows = OPI(w, rows); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.CA = OPI(w, CA); o.CB = OPI(w, CB);
+    o.a_off = OPI(w, a_off); o.a_rs = OPI(w, a_rs); o.a_hw = OPI(w, a_hw); o.a_mod = OPI(w, a_mod); o.a_map_off = OPI(w, a_map_off);
+    o.b_off = OPI(w, b_off); o.b_rs = OPI(w, b_rs); o.a_g = OPP(w, const float, a_g); o.b_g = OPP(w, const float, b_g);
     const int Cd = o.C;                               // padded total channels (multiple of 4)
     const int c4n = Cd >> 2;
     const int total = o.rows * c4n;
@@ -94,7 +122,7 @@ __device__ __forceinline__ void fop_gather(const FOp& o, const UnetArgs& u, int 
                 if ((o.CA & 3) == 0) val = ldg4(p);
                 else
                     for (int j = 0; j < 4; ++j)
-                        if (c + j < o.CA) val[j] = p[j];
+                        if (c + j < o.CA) val[j] = ldg1(p + j);
             }
         } else if (c < o.CA + o.CB) {
             if (o.b_off >= 0) val = *reinterpret_cast<const f32x4*>(lds_f(o.b_off) + (size_t)row * o.b_rs + (c - o.CA));
@@ -106,7 +134,9 @@ __device__ __forceinline__ void fop_gather(const FOp& o, const UnetArgs& u, int 
     }
 }
 
-__device__ __forceinline__ void fop_store(const FOp& o, int n, int tid) {
+__device__ __forceinline__ void fop_store(const OpW& w, int n, int tid) {
+    struct { int C, rows, dst_off, dst_rs; float* g_out; } o;
+    o.C = OPI(w, C); o.rows = OPI(w, rows); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.g_out = OPP(w, float, g_out);
     const int c4n = o.C >> 2;
     const int total = o.rows * c4n;
     const float* src = lds_f(o.dst_off);
@@ -114,7 +144,7 @@ __device__ __forceinline__ void fop_store(const FOp& o, int n, int tid) {
     const int dpv = UW_THREADS / c4n, dc4 = UW_THREADS - dpv * c4n;
     int row = tid / c4n, c4 = tid - row * c4n;
     for (int i = tid; i < total; i += UW_THREADS) {
-        *reinterpret_cast<f32x4*>(g + (size_t)row * o.C + (c4 << 2)) = *reinterpret_cast<const f32x4*>(src + (size_t)row * o.dst_rs + (c4 << 2));
+        stg4(g + (size_t)row * o.C + (c4 << 2), *reinterpret_cast<const f32x4*>(src + (size_t)row * o.dst_rs + (c4 << 2)));
         row += dpv; c4 += dc4;
         if (c4 >= c4n) { c4 -= c4n; ++row; }
     }
@@ -122,60 +152,62 @@ __device__ __forceinline__ void fop_store(const FOp& o, int n, int tid) {
 
 // In-place GroupNorm (two-pass statistics, T lanes per group) + affine (+ SiLU).  stat: LDS scratch [2*G].
 // Work-items keep a FIXED float4 channel column (gamma/beta/group loaded once, before the row loop).
-__device__ __forceinline__ void fop_gn(const FOp& o, float* stat, int tid) {
-    float* X = lds_f(o.dst_off);
-    const int G = o.G, Cg = o.C / G, rs = o.dst_rs;
+__device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid) {
+    float* X = lds_f(OPI(w, dst_off));
+    const int G = OPI(w, G), o_C = OPI(w, C), Cg = o_C / G, rs = OPI(w, dst_rs), o_rows = OPI(w, rows), o_act = OPI(w, act);
+    const float o_eps = OPF(w, eps);
+    const float* o_gamma = OPP(w, const float, gamma); const float* o_beta = OPP(w, const float, beta);
     const int T = UW_THREADS / G;                     // 16 or 32 lanes per group (host-checked power of two <= 64)
     const int g = tid / T, sub = tid - g * T;
-    const float inv_cnt = 1.0f / (float)(Cg * o.rows);
+    const float inv_cnt = 1.0f / (float)(Cg * o_rows);
     const float* base = X + g * Cg;
     float sum = 0.f;
     if ((Cg & 3) == 0) {
-        for (int v = sub; v < o.rows; v += T)
+        for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; cc += 4) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * rs + cc);
                 sum += (q[0] + q[1]) + (q[2] + q[3]);
             }
     } else {
-        for (int v = sub; v < o.rows; v += T)
+        for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * rs + cc];
     }
     for (int m = T >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
     const float mean = sum * inv_cnt;
     float sq = 0.f;
     if ((Cg & 3) == 0) {
-        for (int v = sub; v < o.rows; v += T)
+        for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; cc += 4) {
                 const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * rs + cc);
                 const float d0 = q[0] - mean, d1 = q[1] - mean, d2 = q[2] - mean, d3 = q[3] - mean;
                 sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
     } else {
-        for (int v = sub; v < o.rows; v += T)
+        for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; ++cc) {
                 const float d = base[(size_t)v * rs + cc] - mean;
                 sq += d * d;
             }
     }
     for (int m = T >> 1; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
-    if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o.eps); }
+    if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
     // fixed channel quad per work-item: rows advance by rstep; work-items beyond rstep*c4n idle (C = 192)
-    const int c4n = o.C >> 2;
+    const int c4n = o_C >> 2;
     const int rstep = UW_THREADS / c4n;
     const int r0 = tid / c4n, c = (tid - r0 * c4n) << 2;
     const bool active = r0 < rstep;
     f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
-    if (active) { gm = ldg4(o.gamma + c); bt = ldg4(o.beta + c); }
+    if (active) { gm = ldg4(o_gamma + c); bt = ldg4(o_beta + c); }
     __syncthreads();
     if (active) {
         f32x4 mu, rstd;
         for (int j = 0; j < 4; ++j) { const int gg = (c + j) / Cg; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * gm[j]; }
-        for (int row = r0; row < o.rows; row += rstep) {
+        for (int row = r0; row < o_rows; row += rstep) {
             float* p = X + (size_t)row * rs + c;
             f32x4 val = *reinterpret_cast<f32x4*>(p);
             for (int j = 0; j < 4; ++j) {
                 const float y = (val[j] - mu[j]) * rstd[j] + bt[j];
-                val[j] = o.act ? silu_f(y) : y;
+                val[j] = o_act ? silu_f(y) : y;
             }
             *reinterpret_cast<f32x4*>(p) = val;
         }
@@ -188,32 +220,47 @@ __device__ __forceinline__ int arow(const short* tab, int m, int lds_off, int rs
     return r < 0 ? zero_off : lds_off + r * rs * 4;
 }
 
-// One wave's share of a CONV op: NMT row tiles x one column tile; weights through a PF-deep register ring.
+// One wave's share of a CONV op: NMT row tiles (starting at tile mt0, stride WM) x one column tile.
+//  * weights stream through a PF-deep register ring of straight-line global loads (the compiler waits with
+//    vmcnt(PF-1), never draining the ring); the step count is padded up to a multiple of PF with steps whose A
+//    rows are the zero row, so there is no tail code (instruction-cache footprint matters: the whole interpreter
+//    must stay resident in the 64 KiB I-cache or every op transition refetches cold code);
+//  * A fragments are read from LDS one step ahead of the MFMAs that consume them.
 template <int NMT, int PF>
-__device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int n, int wm, int WM, int nt, int lane) {
+__device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int n, int mt0, int WM, int nt, int lane, long long* fine) {
     const int lrow = lane & 15, kq = lane >> 4;
+    if (fine) fine[0] = clock64();
+    // every op field this wave needs, pinned to scalar registers up front (the descriptor lives in LDS)
+    const int o_rows = OPI(w, rows), o_Cout = OPI(w, Cout), o_Cout_pad = OPI(w, Cout_pad), o_ntap = OPI(w, ntap);
+    const int o_dense = OPI(w, dense_off), o_resid = OPI(w, resid_off), o_resid_rs = OPI(w, resid_rs);
+    const int o_kind = OPI(w, dst_kind), o_dst = OPI(w, dst_off), o_dst_rs = OPI(w, dst_rs);
+    const float o_scale = OPF(w, scale);
+    const int m_lds = OPI(w, main_ph.lds_off), m_rs = OPI(w, main_ph.rs), nch = OPI(w, main_ph.nch);
+    const float* m_w = OPP(w, const float, main_ph.w);
+    const float* o_bias = OPP(w, const float, bias); const float* o_bias2 = OPP(w, const float, bias2);
+    float* o_gout = OPP(w, float, g_out);
+    const int tab_word = (int)(offsetof(FOp, tab_off) / 4);
+    const int zero_off = u.zero_off;
     const int col = nt * 16 + lrow;
     f32x4 acc[NMT];
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int mrow[NMT];
 #pragma unroll
-    for (int i = 0; i < NMT; ++i) mrow[i] = (wm + i * WM) * 16 + lrow;
+    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + lrow;
     // epilogue operands are fetched now so their global latency hides under the GEMM
     float add = 0.f;
-    if (col < o.Cout) {
-        add = ldg1(o.bias + col);
-        if (o.bias2) add += ldg1(o.bias2 + col);
-        if (o.dense_off >= 0) add += ldg1(u.dense + (size_t)n * u.dense_stride + o.dense_off + col);
+    if (col < o_Cout) {
+        add = ldg1(o_bias + col);
+        if (o_bias2) add += ldg1(o_bias2 + col);
+        if (o_dense >= 0) add += ldg1(u.dense + (size_t)n * u.dense_stride + o_dense + col);
     }
-
-    // ---- main phases (taps): flattened step q = tap * nch + chunk.
-    // Ring refills are UNCONDITIONAL straight-line loads (index clamped at the end), so the compiler can count the
-    // outstanding loads and wait with vmcnt(PF-1) instead of draining the ring at every branch.
     {
-        const int nch = o.main_ph.nch, nsteps = o.ntap * nch;
-        const size_t bstride = (size_t)o.Cout_pad * 16;
-        const float* Wl = o.main_ph.w + (size_t)col * 16 + kq * 4;
+        const int nsteps = o_ntap * nch;
+        const int npad = ((nsteps + PF - 1) / PF) * PF;
+        const size_t bstride = (size_t)o_Cout_pad * 16;
+        const float* Wl = m_w + (size_t)col * 16 + kq * 4;
         f32x4 ring[PF];
 #pragma unroll
         for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nsteps - 1) * bstride);
@@ -221,130 +268,112 @@ __device__ __forceinline__ void fconv_wave(const FOp& o, const UnetArgs& u, int 
         int abase[NMT];
 #pragma unroll
         for (int i = 0; i < NMT; ++i)
-            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[0]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
-        const int nfull = (nsteps / PF) * PF;
-        for (int q = 0; q < nfull; q += PF) {
+            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
+        f32x4 afn[NMT];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i]);
+        if (fine) fine[1] = clock64();
+        for (int q = 0; q < npad; q += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
                 f32x4 af[NMT];
 #pragma unroll
-                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+                for (int i = 0; i < NMT; ++i) af[i] = afn[i];
+                // advance to the next step and issue its A reads before this step's MFMAs
+                if (++ch == nch) {
+                    ch = 0; ++ph;
+                    if (ph < o_ntap) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                        for (int i = 0; i < NMT; ++i)
+                            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word + ph)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                        for (int i = 0; i < NMT; ++i) abase[i] = zero_off + kq * 16;     // padding steps contribute 0
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+                if (NMT == 1) {     // single row tile: alternate two accumulators so the MFMAs are not a dependent chain
+                    acc[0] = mfma16(af[0][0], ring[p][0], acc[0]); acc2 = mfma16(af[0][1], ring[p][1], acc2);
+                    acc[0] = mfma16(af[0][2], ring[p][2], acc[0]); acc2 = mfma16(af[0][3], ring[p][3], acc2);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                }
                 ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nsteps - 1) * bstride);
-                if (++ch == nch) {
-                    ch = 0; ++ph;
-                    if (ph < o.ntap) {
-#pragma unroll
-                        for (int i = 0; i < NMT; ++i)
-                            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[ph]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            if (nfull + p < nsteps) {
-                f32x4 af[NMT];
-#pragma unroll
-                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
-                if (++ch == nch) {
-                    ch = 0; ++ph;
-                    if (ph < o.ntap) {
-#pragma unroll
-                        for (int i = 0; i < NMT; ++i)
-                            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + o.tab_off[ph]), mrow[i], o.main_ph.lds_off, o.main_ph.rs, u.zero_off) + kq * 16;
-                    }
-                }
             }
         }
     }
-    // ---- shortcut phases (raw block input through NIN_0)
-    for (int s = 0; s < o.nsc; ++s) {
-        const FPhase& ph = o.sc[s];
-        const int nch = ph.nch;
-        const size_t bstride = (size_t)o.Cout_pad * 16;
-        const float* Wl = ph.w + (size_t)col * 16 + kq * 4;
-        int abase[NMT];
-#pragma unroll
-        for (int i = 0; i < NMT; ++i)
-            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + ph.tab_off), mrow[i], ph.lds_off, ph.rs, u.zero_off) + kq * 16;
-        f32x4 ring[PF];
-#pragma unroll
-        for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nch - 1) * bstride);
-        const int nfull = (nch / PF) * PF;
-        for (int q = 0; q < nfull; q += PF) {
-#pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                f32x4 af[NMT];
-#pragma unroll
-                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + (q + p) * 64);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
-                ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nch - 1) * bstride);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            if (nfull + p < nch) {
-                f32x4 af[NMT];
-#pragma unroll
-                for (int i = 0; i < NMT; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + (nfull + p) * 64);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
-            }
-        }
-    }
-    // ---- epilogue
-    if (col < o.Cout || o.dst_kind == 1) {
+    if (NMT == 1) acc[0] += acc2;
+    if (fine) fine[4] = clock64();
+    // ---- epilogue: three destinations, each its own (wave-uniform) branch so LDS stores stay ds_write and global
+    //      stores stay global_store (a merged pointer would degrade both to flat_store)
+    if (o_kind == 1) {                        // LDS, transposed [col][row]; all padded rows written (finite)
+        float* dstp = lds_f(o_dst);
 #pragma unroll
         for (int i = 0; i < NMT; ++i) {
-            const int row0 = (wm + i * WM) * 16 + kq * 4;
-            if (o.dst_kind == 1) {                    // transposed [col][row], all padded rows written (finite)
-                f32x4 v = acc[i];
-                for (int r = 0; r < 4; ++r) v[r] = (v[r] + add) * o.scale;
-                *reinterpret_cast<f32x4*>(lds_f(o.dst_off) + (size_t)col * o.dst_rs + row0) = v;
-            } else {
+            const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+            f32x4 v = acc[i];
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] + add) * o_scale;
+            *reinterpret_cast<f32x4*>(dstp + col * o_dst_rs + row0) = v;
+        }
+    } else if (col < o_Cout) {
+        float rv[NMT][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + r;
-                    if (row >= o.rows) continue;
-                    float v = acc[i][r] + add;
-                    if (o.resid_off >= 0) v += lds_f(o.resid_off)[(size_t)row * o.resid_rs + col];
-                    v *= o.scale;
-                    if (o.dst_kind == 0) lds_f(o.dst_off)[(size_t)row * o.dst_rs + col] = v;
-                    else (o.g_out ? o.g_out : u.out)[((size_t)n * o.rows + row) * o.Cout + col] = v;
-                }
+        for (int i = 0; i < NMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[i][r] = 0.f;
+        if (o_resid >= 0) {
+            const float* resp = lds_f(o_resid);
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < o_rows) rv[i][r] = resp[(row0 + r) * o_resid_rs + col];
+            }
+        }
+        if (o_kind == 0) {
+            float* dstp = lds_f(o_dst);
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + col] = (acc[i][r] + add + rv[i][r]) * o_scale;
+            }
+        } else {
+            float* gp = (o_gout ? o_gout : u.out) + (size_t)n * o_rows * o_Cout + col;
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < o_rows) stg1(gp + (row0 + r) * o_Cout, (acc[i][r] + add + rv[i][r]) * o_scale);
             }
         }
     }
+    if (fine) fine[5] = clock64();
 }
 
-__device__ __forceinline__ void fop_conv(const FOp& o, const UnetArgs& u, int n, int wave, int lane) {
-    const int ntiles = __builtin_amdgcn_readfirstlane(o.Cout_pad >> 4);
-    const int WN = ntiles >= 8 ? 8 : (ntiles >= 4 ? 4 : (ntiles >= 2 ? 2 : 1));
-    const int WM = UW_WAVES / WN;
-    const int wn = wave % WN, wm = wave / WN;
-    const int nmt = __builtin_amdgcn_readfirstlane(o.mtiles > wm ? (o.mtiles - wm + WM - 1) / WM : 0);
+__device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n, int wave, int lane, long long* fine) {
+    const int ntiles = OPI(w, Cout_pad) >> 4, mtiles = OPI(w, mtiles);
+    const int lWN = ntiles >= 8 ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // log2 of waves along N
+    const int WN = 1 << lWN, WM = UW_WAVES >> lWN, lWM = 3 - lWN;
+    const int wn = wave & (WN - 1), wm = wave >> lWN;
     for (int nt = wn; nt < ntiles; nt += WN) {
-        switch (nmt) {
-            case 1: fconv_wave<1, 16>(o, u, n, wm, WM, nt, lane); break;
-            case 2: fconv_wave<2, 8>(o, u, n, wm, WM, nt, lane); break;
-            case 3: fconv_wave<3, 8>(o, u, n, wm, WM, nt, lane); break;
-            case 4: fconv_wave<4, 6>(o, u, n, wm, WM, nt, lane); break;
-            case 5: fconv_wave<5, 4>(o, u, n, wm, WM, nt, lane); break;
-            case 6: fconv_wave<6, 4>(o, u, n, wm, WM, nt, lane); break;
-            default: break;
+        // this wave's row tiles wm, wm+WM, ... in groups of at most 4 (only NMT 1..4 are instantiated)
+        for (int mt0 = wm; mt0 < mtiles; mt0 += 4 * WM) {
+            const int left = (mtiles - mt0 + WM - 1) >> lWM;
+            switch (left >= 4 ? 4 : left) {
+                case 1: fconv_wave<1, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 2: fconv_wave<2, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 3: fconv_wave<3, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 4: fconv_wave<4, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
+                default: break;
+            }
         }
     }
 }
@@ -352,7 +381,10 @@ __device__ __forceinline__ void fop_conv(const FOp& o, const UnetArgs& u, int n,
 // Attention core on LDS tensors: P = softmax(Q K^T * scale) (rows = queries), O = P V.
 // Q, K: [L][qk_rs]; Vt: [C][ps] (keys along the row, all Lpad columns finite); P: [L][ps]; O -> dst [L][dst_rs].
 // C = 64 channels (one 16-wide channel tile per wave pair).
-__device__ __forceinline__ void fop_attn(const FOp& o, int wave, int lane) {
+__device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
+    struct { int L, Lpad, q_off, k_off, vt_off, p_off, qk_rs, ps, C, dst_off, dst_rs; float att_scale; } o;
+    o.L = OPI(w, L); o.Lpad = OPI(w, Lpad); o.q_off = OPI(w, q_off); o.k_off = OPI(w, k_off); o.vt_off = OPI(w, vt_off); o.p_off = OPI(w, p_off);
+    o.qk_rs = OPI(w, qk_rs); o.ps = OPI(w, ps); o.C = OPI(w, C); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.att_scale = OPF(w, att_scale);
     const int lrow = lane & 15, kq = lane >> 4;
     const int L = o.L, mtiles = o.Lpad >> 4;
     const float* Q = lds_f(o.q_off);
@@ -452,26 +484,25 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         for (int i = tid; i < (u.zero_bytes >> 2); i += UW_THREADS) z[i] = 0.f;
     }
     float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
-    // Op descriptors are staged in LDS, one op ahead (2 slots after the GN scratch): field reads inside the loops
-    // are then LDS reads (lgkmcnt) instead of global reads that would force vmcnt(0) under the weight ring.
-    constexpr int OPW = (int)(sizeof(FOp) / 4);
-    int* opslot = reinterpret_cast<int*>(stat + 64);
-    if (tid < OPW) opslot[tid] = reinterpret_cast<const int*>(u.prog)[tid];
-    __syncthreads();
     if (u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
+    OpW cur = opw_load(u.prog, lane);
     for (int pc = 0; pc < u.nops; ++pc) {
-        if (pc + 1 < u.nops && tid < OPW) opslot[((pc + 1) & 1) * OPW + tid] = reinterpret_cast<const int*>(u.prog + pc + 1)[tid];
-        const FOp& o = *reinterpret_cast<const FOp*>(opslot + (pc & 1) * OPW);
-        const int kind = __builtin_amdgcn_readfirstlane(o.kind);
+        // next op's descriptor words: issued now, consumed next iteration (latency hides under this op)
+        const OpW nxt = opw_load(u.prog + (pc + 1 < u.nops ? pc + 1 : pc), lane);
+        long long* fine = (u.stamps && n == 0 && tid == 0) ? u.stamps + 1024 + pc * 8 : nullptr;
+        const int kind = OPI(cur, kind);
+        if (fine) fine[2] = clock64();
+        if (fine) fine[3] = clock64();
         switch (kind) {
-            case FOP_GATHER: fop_gather(o, u, n, tid); break;
-            case FOP_STORE: fop_store(o, n, tid); break;
-            case FOP_GN: fop_gn(o, stat, tid); break;
-            case FOP_CONV: fop_conv(o, u, n, wave, lane); break;
-            case FOP_ATTN: fop_attn(o, wave, lane); break;
+            case FOP_GATHER: fop_gather(cur, u, n, tid); break;
+            case FOP_STORE: fop_store(cur, n, tid); break;
+            case FOP_GN: fop_gn(cur, stat, tid); break;
+            case FOP_CONV: fop_conv(cur, u, n, wave, lane, fine); break;
+            case FOP_ATTN: fop_attn(cur, wave, lane); break;
             default: break;
         }
         __syncthreads();
         if (u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
+        cur = nxt;
     }
 }

@@ -186,9 +186,10 @@ class Context:
         return buf[:nb * n].reshape(nb, c.value, h.value, w.value).clone()
 
     def op_cycles(self):
-        cyc = (C.c_longlong * 512)()
+        cyc = (C.c_longlong * 2048)()
         desc = (C.c_char_p * 512)()
-        n = lib().rdmi_debug_op_cycles(self._h, cyc, 512, desc, 512)
+        n = lib().rdmi_debug_op_cycles(self._h, cyc, 2048, desc, 512)
+        self.fine = [[int(cyc[256 + i * 6 + k]) for k in range(6)] for i in range(min(n, 250))]
         return [(desc[i].decode(), int(cyc[i])) for i in range(n)]
 
     def path_info(self):

@@ -23,7 +23,7 @@ ops = ctx.op_cycles()
 tot = sum(c for _, c in ops)
 agg = {}
 for i, (d, c) in enumerate(ops):
-    print(f'{i:3d} {c:8d} {100*c/tot:5.1f}%  {d}')
+    print(f'{i:3d} {c:8d} {100*c/tot:5.1f}%  {d}' + (f'   fine(entry,ring,kind,prefetch,main,epi)={ctx.fine[i]}' if d.startswith('CONV') and i < len(ctx.fine) else ''))
     k = d.split()[0] + (' ' + d.split()[1] if d.startswith('CONV') else '')
     agg[k] = agg.get(k, 0) + c
 print('total cycles', tot, ' (100 MHz ticks?)')

@@ -83,6 +83,8 @@ inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_em
 }
 
 inline long long clock64() { return 0; }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+template <class T, class U> inline T __builtin_bit_cast_emu(U u) { T t; std::memcpy(&t, &u, sizeof(T)); return t; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
