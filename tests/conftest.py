@@ -29,3 +29,16 @@ def golden():
 def params0():
     from oracle.weights import make_params
     return make_params(0)
+
+
+@pytest.fixture(scope='module')
+def emu():
+    """Bind rdmi to the CPU emulator build of the SAME csrc sources for this test module, then restore.
+    (Test infrastructure: the product only ever loads librdmi.so.)"""
+    from tests.emu.build_emu import build
+    from rdmi import _native
+    prev = (_native._lib, _native._lib_path)
+    _native.use_library(build())
+    assert _native.is_emulator()
+    yield _native
+    _native._lib, _native._lib_path = prev

@@ -1,0 +1,133 @@
+"""Host-side mirror of the reference interface: registries, error behaviour, parameter layout/initialisation,
+EMA arithmetic, SDE schedule -- no kernels involved (CPU)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_model_registry_semantics():
+    from rdmi.models import utils as mutils
+    assert mutils.get_model('ncsnpp').__name__ == 'NCSNpp'
+    with pytest.raises(ValueError, match='Already registered'):
+        @mutils.register_model(name='ncsnpp')
+        class Dup:                                   # noqa
+            pass
+
+    @mutils.register_model
+    class _TmpModelForTest:                          # bare decorator form registers under the class name
+        pass
+    assert mutils.get_model('_TmpModelForTest') is _TmpModelForTest
+    with pytest.raises(KeyError):
+        mutils.get_model('nope')
+
+
+def test_sampler_registries_and_dispatch():
+    from types import SimpleNamespace as NS
+    from rdmi import sampling, sde_lib
+    assert sampling.get_predictor('euler_maruyama') is sampling.ReflectedEulerMaruyamaPredictor
+    assert sampling.get_corrector('langevin') is sampling.ReflectedLangevinCorrector
+    assert sampling.get_corrector('none') is sampling.NoneCorrector
+    assert {k: sampling.get_denoiser(k).__name__ for k in ('network', 'mean', 'none')} == \
+        {'network': 'TrainedDenoiser', 'mean': 'MeanDenoiser', 'none': 'NoneDenoiser'}
+    with pytest.raises(KeyError):
+        sampling.get_predictor('ancestral')
+    with pytest.raises(ValueError, match='Already registered'):
+        sampling.register_corrector(name='langevin')(type('X', (), {}))
+    cfg = NS(sampling=NS(method='bogus'))
+    with pytest.raises(ValueError, match='unknown'):
+        sampling.get_sampling_fn(cfg, sde_lib.RVESDE(0.01, 5, N=10), (2, 1, 9, 9), 1e-5, 'cpu')
+    cfg = NS(sampling=NS(method='pc', predictor='euler_maruyama', corrector='none', denoiser='none', snr=0.01, n_steps_each=1))
+    fn = sampling.get_sampling_fn(cfg, sde_lib.RVESDE(0.01, 5, N=10), (2, 1, 9, 9), 1e-5, 'cpu')
+    assert callable(fn)
+    x = torch.rand(2, 1, 9, 9)
+    assert sampling.NoneCorrector(None, None, 0.1, 1).update_fn(x, None)[0] is x
+    assert sampling.MeanDenoiser(None).update_fn(x, x + 1, None).equal(x + 1)
+
+
+def test_state_dict_layout_and_reference_init(golden):
+    """261 names in the reference's registration order; seeded init consumes the torch RNG exactly like the reference
+    (bit-identical parameters under torch.manual_seed(0)): fixture recorded from the reference."""
+    import __graft_entry__ as ge
+    from rdmi.models import utils as mutils
+    g = golden('init_seed0.npz')
+    torch.manual_seed(0)
+    model = mutils.create_model(ge.demo_config())
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g['names'])
+    assert sum(v.numel() for v in sd.values()) == 6254913
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode()); h.update(v.numpy().tobytes())
+    assert h.digest() == bytes(g['sha256'])
+    assert [n for n, p in model.named_parameters() if not p.requires_grad] == ['time_embed.W']
+
+
+def test_unsupported_configs_fail_loudly():
+    import __graft_entry__ as ge
+    from rdmi.models import utils as mutils
+    cfg = ge.demo_config(); cfg.model.nonlinearity = 'elu'
+    with pytest.raises(NotImplementedError):
+        mutils.create_model(cfg)
+    cfg = ge.demo_config(); cfg.model.fir = True
+    with pytest.raises(NotImplementedError):
+        mutils.create_model(cfg)
+    cfg = ge.demo_config(); cfg.model.embedding_type = 'positional'
+    with pytest.raises(NotImplementedError, match='fourier'):
+        mutils.create_model(cfg)
+
+
+def test_ema_matches_reference_formula():
+    from rdmi.models.ema import ExponentialMovingAverage
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2), requires_grad=False)]
+    ema = ExponentialMovingAverage(ps, decay=0.999)
+    assert len(ema.shadow_params) == 2
+    shadow = [p.detach().clone() for p in ps[:2]]
+    for step in range(1, 6):
+        with torch.no_grad():
+            for p in ps[:2]:
+                p.add_(0.1 * torch.randn_like(p))
+        ema.update(ps)
+        d = min(0.999, (1 + step) / (10 + step))
+        for s, p in zip(shadow, ps[:2]):
+            s.sub_((1.0 - d) * (s - p.detach()))
+        for a, b in zip(ema.shadow_params, shadow):
+            assert torch.equal(a, b)
+    before = [p.detach().clone() for p in ps]
+    ema.store(ps); ema.copy_to(ps)
+    assert torch.equal(ps[0].detach(), ema.shadow_params[0]) and torch.equal(ps[2].detach(), before[2])
+    ema.restore(ps)
+    assert all(torch.equal(a.detach(), b) for a, b in zip(ps, before))
+    sd = ema.state_dict()
+    assert set(sd) == {'decay', 'num_updates', 'shadow_params'} and sd['num_updates'] == 5
+    with pytest.raises(ValueError):
+        ExponentialMovingAverage(ps, decay=1.5)
+
+
+def test_rvesde_schedule(golden):
+    from rdmi import sde_lib
+    g = golden('cube_sde.npz')
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    t = torch.from_numpy(g['sde_t'])
+    x = torch.zeros(t.numel(), 1, 9, 9)
+    assert np.array_equal(sde.marginal_prob(x, t)[1].numpy(), g['sde_sigma'])
+    drift, diff = sde.sde(x, t)
+    assert np.array_equal(diff.numpy(), g['sde_g']) and float(drift.abs().max()) == 0
+    assert sde.T == 1 and sde.prior_sampling((2, 3)).shape == (2, 3) and float(sde.prior_logp(x).abs().max()) == 0
+    rs = sde.reverse(lambda xx, tt: torch.ones_like(xx), probability_flow=True)
+    d, gdiff = rs.sde(x, t)
+    np.testing.assert_allclose(d[:, 0, 0, 0].numpy(), -0.5 * g['sde_g'] ** 2, rtol=1e-6)
+    assert float(gdiff.abs().max()) == 0
+    f, G = sde.discretize(x, t)
+    assert G.shape == t.shape and float(f.abs().max()) == 0
+
+
+def test_flatten_helpers_and_sigmas():
+    from types import SimpleNamespace as NS
+    from rdmi.models import utils as mutils
+    x = torch.arange(12.).reshape(3, 4)
+    assert mutils.from_flattened_numpy(mutils.to_flattened_numpy(x), (3, 4)).equal(x)
+    s = mutils.get_sigmas(NS(sde=NS(sigma_max=5, sigma_min=0.01, num_scales=7)))
+    assert s.shape == (7,) and np.isclose(s[0], 5) and np.isclose(s[-1], 0.01)
