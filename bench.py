@@ -139,6 +139,7 @@ def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, 
     torch.cuda.synchronize()
     prof = ctx.get_profile()
     ctx.set_profiling(False)
+    plan = ctx.path_info()
     total_ms = sum(p['ms'] for p in prof)
     dom = max(prof, key=lambda p: p['ms'])
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
@@ -148,7 +149,7 @@ def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, 
     hbm_bytes_per_traj = fwd_per_traj * ACT_BYTES_PER_FORWARD + (fwd_per_traj / 2) * WEIGHT_BYTES / shape[0]
     return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-            'avg_launch_us': 1e3 * dom['ms'] / max(dom['launches'], 1), 'launches': dom['launches'],
+            'avg_launch_us': 1e3 * dom['ms'] / max(dom['launches'], 1), 'launches': dom['launches'], 'plan': plan,
             'whole_path_frac_of_fp32_peak': traj_per_s_per_gpu * fwd_per_traj * GFLOP_PER_FORWARD / 1e3 / PEAK_FP32_MFMA_TFLOPS,
             'whole_path_layer_granular_hbm_frac': traj_per_s_per_gpu * hbm_bytes_per_traj / 1e9 / PEAK_HBM_GBPS,
             'kernels': kernels}

@@ -227,3 +227,49 @@ def test_full_size_properties(env):
         s = mutils.get_cf_score_fn(sde, model, lab, 0.0)(x, t).cpu().numpy()
     ref = O.cf_score_fn(params, O.RVESDE(0.01, 5, N=N), prior.numpy(), t.cpu().numpy(), lab.cpu().numpy(), 0.0)
     np.testing.assert_allclose(s, ref, rtol=0, atol=2e-4)
+
+
+def test_both_execution_plans_agree(env, golden):
+    """The workgroup-resident fused U-Net (default) and the layer-by-layer plan compute the same function."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    dev, ge = env['dev'], env['ge']
+    assert env['model'].native_context(16, 9, 9, dev).path_info().startswith('fused')
+    os.environ['RDMI_PATH'] = 'layers'
+    try:
+        m2, _, _ = ge.make_model(dev)
+        ctx2 = m2.native_context(256, 9, 9, dev)
+    finally:
+        os.environ.pop('RDMI_PATH', None)
+    assert ctx2.path_info().startswith('layers')
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    g = torch.Generator().manual_seed(8)
+    B = 128
+    x = torch.rand(B, 1, 9, 9, generator=g).to(dev); t = (torch.rand(B, generator=g) * 0.99 + 0.01).to(dev)
+    lab = torch.rand(B, 1, generator=g).to(dev)
+    with torch.no_grad():
+        a = mutils.get_cf_score_fn(sde, env['model'], lab, 0.3)(x, t)
+        b = mutils.get_cf_score_fn(sde, m2, lab, 0.3)(x, t)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-5)
+    gg = golden('forward_9x9.npz')
+    with torch.no_grad():
+        s = mutils.get_score_fn(sde, m2)(T(gg['x'], dev), T(gg['t'], dev), class_labels=T(gg['labels'], dev))
+    np.testing.assert_allclose(s.cpu().numpy(), gg['score'], rtol=0, atol=2e-4)
+
+
+def test_large_batch_many_workgroups(env):
+    """More samples than CUs (B=600 -> 600 workgroups, 2.3 waves of the chip) and a batch that is not a multiple of anything."""
+    from oracle import rd_oracle as O
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    dev, model, params = env['dev'], env['model'], env['params']
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    g = torch.Generator().manual_seed(9)
+    B = 601
+    x = torch.rand(B, 1, 9, 9, generator=g); t = torch.rand(B, generator=g) * 0.99 + 0.01; lab = torch.rand(B, 1, generator=g)
+    with torch.no_grad():
+        s = mutils.get_score_fn(sde, model)(x.to(dev), t.to(dev), class_labels=lab.to(dev)).cpu().numpy()
+    idx = [0, 255, 256, 300, 599, 600]
+    ref = O.score_fn(params, O.RVESDE(0.01, 5, N=1000), x.numpy()[idx], t.numpy()[idx], lab.numpy()[idx])
+    np.testing.assert_allclose(s[idx], ref, rtol=0, atol=2e-4)
+    assert np.isfinite(s).all()
