@@ -59,6 +59,7 @@ struct LinArgs {
     int pre;
     // pre == 2: X = sigma (or sde-time t when t_is_time) of sample (row % x_mod)
     const float* fourW; int nfour; int x_mod; int t_is_time; float smin, ratio;
+    int use_scalar; float t_scalar;                 // X == null: every row uses this one time (the PC loop, RD/sampling.py:329)
     // optional label embedding added in the epilogue: labels [label_rows][ncls] (rows beyond are zero labels)
     const float* labels; const float* Wl; const float* bl; int ncls; int label_rows;
 };
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void linear_mfma_kernel(LinArgs a) {
     const int col = blockIdx.y * 64 + wave * 16 + lrow;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float ls = 0.f;
-    if (a.pre == 2 && row < a.M) ls = logf(sigma_of(a.X[row % a.x_mod], a.t_is_time, a.smin, a.ratio));
+    if (a.pre == 2 && row < a.M) ls = logf(sigma_of(a.use_scalar ? a.t_scalar : a.X[row % a.x_mod], a.t_is_time, a.smin, a.ratio));
     for (int ch = 0; ch < (a.K >> 4); ++ch) {
         const f32x4 bf = *reinterpret_cast<const f32x4*>(a.W + ((size_t)ch * a.Npad + col) * 16 + kq * 4);
         f32x4 af = {0.f, 0.f, 0.f, 0.f};
@@ -202,6 +203,50 @@ __global__ __launch_bounds__(RDMI_THREADS) void em_update_kernel(
     x_out[i] = xr;
     if (x_mean_out) x_mean_out[i] = reflect_f(xm);
     if (trace) trace[(long)st->step * B * E + i] = xr;
+}
+
+// One launch per predictor update: CFG combine + N(0,1) draw (in-kernel Philox or injected) + reflected
+// Euler-Maruyama + trace / teacher forcing.  s: [2B][E] (use_cfg) or [B][E] scores straight from the network.
+__global__ __launch_bounds__(RDMI_THREADS) void em_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ z,
+    float* __restrict__ x_out, float* __restrict__ trace, const float* __restrict__ teacher,
+    int B, int E, int N, float t, float smin, float ratio, float gconst, int use_cfg, uint64_t seed, uint64_t elem_offset, uint32_t draw) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)B * E) return;
+    float score = s[i];
+    if (use_cfg) { const float wt = w ? w[i / E] : 0.f; score = (1.0f + wt) * score - wt * s[(long)B * E + i]; }
+    float zz;
+    if (z) zz = z[i];
+    else { const uint64_t g = elem_offset + (uint64_t)i; zz = philox_normal4(seed, g >> 2, draw)[(int)(g & 3)]; }
+    const float sigma = smin * powf(ratio, t);
+    const float g_ = sigma * gconst;
+    const float dt = -1.0f / (float)N;
+    const float drift = 0.0f - (g_ * g_) * score;
+    const float xm = x[i] + drift * dt;
+    const float xr = reflect_f(xm + (g_ * sqrtf(-dt)) * zz);
+    if (trace) trace[i] = xr;
+    x_out[i] = teacher ? teacher[i] : xr;
+}
+
+// Langevin, launch 1 of 2: per-sample CFG-combined score (stored), noise (stored) and their L2 norms.
+__global__ __launch_bounds__(64) void langevin_prep_kernel(
+    const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ z_in, float* __restrict__ score_out,
+    float* __restrict__ z_out, float* __restrict__ norms, int B, int E, int use_cfg, uint64_t seed, uint64_t elem_offset, uint32_t draw) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float wt = (use_cfg && w) ? w[b] : 0.f;
+    float s2 = 0.f, z2 = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const long i = (long)b * E + e;
+        float sc = s[i];
+        if (use_cfg) sc = (1.0f + wt) * sc - wt * s[(long)B * E + i];
+        float zz;
+        if (z_in) zz = z_in[i];
+        else { const uint64_t g = elem_offset + (uint64_t)i; zz = philox_normal4(seed, g >> 2, draw)[(int)(g & 3)]; }
+        score_out[i] = sc; z_out[i] = zz;
+        s2 += sc * sc; z2 += zz * zz;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { s2 += __shfl_xor(s2, m); z2 += __shfl_xor(z2, m); }
+    if (lane == 0) { norms[b] = sqrtf(s2); norms[B + b] = sqrtf(z2); }
 }
 
 // Langevin corrector, part 1: per-sample L2 norms of score and noise (RD/sampling.py:225-226).

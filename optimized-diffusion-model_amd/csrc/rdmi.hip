@@ -402,6 +402,17 @@ struct Builder {
             c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
         }
         c->wmap[name + ".qkv"] = op.w_off;
+        {   // fused-plan packing: q|k|v side by side as one [C/16][3C][16] matrix
+            const size_t o3 = alloc_w((size_t)3 * C * C);
+            for (int i = 0; i < 3; ++i) {
+                PackJob j{};
+                j.dst = reinterpret_cast<float*>(o3);
+                j.Cin = C; j.Cout = C; j.Kpad = C; j.Npad = 3 * C; j.n_off = i * C; j.ntap = 1; j.s_co = 1; j.s_ci = C; j.s_t = 0; j.kind = 0;
+                c->jobs.push_back(j);
+                c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
+            }
+            c->wmap[name + ".qkv3"] = o3;
+        }
         op.bqkv_off = alloc_w((size_t)3 * C);
         c->wmap[name + ".bqkv"] = op.bqkv_off;
         for (int i = 0; i < 3; ++i) job_copy(name + ".NIN_" + std::to_string(i) + ".b", op.bqkv_off, C, i * C);
@@ -734,7 +745,7 @@ struct FusedBuilder {
     FOp blank(int kind) {
         FOp o;
         std::memset(&o, 0, sizeof o);
-        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f;
+        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1;
         return o;
     }
     int emit(const FOp& o) { c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
@@ -775,8 +786,9 @@ struct FusedBuilder {
         spill_fix.push_back({idx, off, false});
         return off;
     }
-    void gn(const LT& t, const std::string& pre, bool act) {
+    void gn(const LT& t, const std::string& pre, bool act, const LT* src = nullptr) {
         FOp o = blank(FOP_GN);
+        if (src) { o.src_off = src->off; o.src_rs = src->rs; }
         o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
         o.G = std::min(t.C / 4, 32); o.act = act ? 1 : 0; o.eps = 1e-6f;
         if (t.C % o.G != 0 || UW_THREADS % o.G != 0 || UW_THREADS / o.G > 64) fail_("GroupNorm shape C=" + std::to_string(t.C));
@@ -834,8 +846,7 @@ FusedBuilder::LT fused_resblock(FusedBuilder& b, const std::string& name, FusedB
         return out;
     }
     LT xact = b.talloc(xin.C, H, W);
-    b.copy_t(xact, xin);
-    b.gn(xact, name + ".GroupNorm_0", true);
+    b.gn(xact, name + ".GroupNorm_0", true, &xin);
     LT h1 = b.talloc(cout, H, W);
     b.conv(xact, H, W, H, W, 1, 1, 9, name + ".Conv_0", 0, cout, name + ".Conv_0.bias", 0, 0, &h1, 1.f, dense_off, nullptr, nullptr, "", "");
     b.tfree(xact);
@@ -854,18 +865,18 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
     const int C = x.C, H = x.H, W = x.W, L = H * W, Lpad = pad16(L);
     if (C != 64 || Lpad > 96) { b.fail_("attention: only C=64, H*W<=96 is built"); return x; }
     LT xn = b.talloc(C, H, W);
-    b.copy_t(xn, x);
-    b.gn(xn, name + ".GroupNorm_0", false);
+    b.gn(xn, name + ".GroupNorm_0", false, &x);
     LT q = b.talloc(C, H, W), k = b.talloc(C, H, W);
     const int ps = Lpad + 4;
     const int vt_bytes = C * ps * 4, p_bytes = L * ps * 4;
     const int vt_off = b.alloc_top(vt_bytes);
-    LT vt; vt.off = vt_off; vt.rs = ps; vt.C = C;
-    const size_t CC = (size_t)C * C;
     const size_t bq = c->wmap.at(name + ".bqkv");
-    b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv", 0, C, "", bq, 0, &q, 1.f, -1, nullptr, nullptr, "", "");
-    b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv", CC, C, "", bq + C, 0, &k, 1.f, -1, nullptr, nullptr, "", "");
-    b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv", 2 * CC, C, "", bq + 2 * C, 1, &vt, 1.f, -1, nullptr, nullptr, "", "");
+    {   // q, k, v in one contraction: the layer plan already packs NIN_0..2 side by side? no: [3][C/16][C][16] -> use the
+        // dedicated fused packing [C/16][3C][16] (wmap key ".qkv3")
+        const int idx = b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv3", 0, 3 * C, "", bq, 3, &q, 1.f, -1, nullptr, nullptr, "", "");
+        FOp& o = c->fprog[(size_t)idx];
+        o.dst2_off = k.off; o.dst3_off = vt_off; o.dst3_rs = ps; o.split_C = C;
+    }
     b.tfree(xn);
     const int p_off = b.alloc_top(p_bytes);
     LT o = b.talloc(C, H, W);
@@ -1142,7 +1153,8 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
 
 struct FwdIn {
     const float* x; int x_mod;            // x holds x_mod samples; sample n reads x[n % x_mod] (0: n)
-    const float* sig; int sig_mod;        // sigma or t per sample (n % sig_mod); null with st: ts[st->step]
+    const float* sig; int sig_mod;        // sigma or t per sample (n % sig_mod); null: every sample uses t_scalar
+    float t_scalar;
     int t_is_time; float smin, ratio;
     const float* labels; int label_rows;
     float* out; int NB;
@@ -1158,6 +1170,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     LinArgs l{};
     l.M = f.NB; l.fourW = P(c, "time_embed.W"); l.nfour = a.nf;
     l.X = f.sig; l.x_mod = f.sig_mod > 0 ? f.sig_mod : f.NB; l.t_is_time = f.t_is_time; l.smin = f.smin; l.ratio = f.ratio;
+    l.use_scalar = f.sig ? 0 : 1; l.t_scalar = f.t_scalar;
     l.pre = 2; l.K = pad16(2 * a.nf); l.W = c->d_w + c->w_t0; l.Npad = Np_t; l.N = T; l.bias = P(c, "time_mlp.0.bias");
     l.Y = c->d_h1; l.ldy = T;
     {
@@ -1316,7 +1329,7 @@ int rdmi_forward(rdmi_ctx* c, const float* x, const float* sigma, const float* l
     if (!c || !x || !sigma || !out) return fail("null argument");
     hipStream_t s = (hipStream_t)stream;
     if (int e = maybe_repack(c, flags, s)) return e;
-    FwdIn f{x, 0, sigma, 0, 0, 0.f, 0.f, labels, B, out, B};
+    FwdIn f{x, 0, sigma, 0, 0.f, 0, 0.f, 0.f, labels, B, out, B};
     int e = run_forward(c, f, s);
     if (c->profiling) prof_collect(c);
     return e;
@@ -1327,7 +1340,7 @@ int rdmi_score(rdmi_ctx* c, const float* x, const float* t, const float* labels,
     if (!c || !x || !t || !out) return fail("null argument");
     hipStream_t s = (hipStream_t)stream;
     if (int e = maybe_repack(c, flags, s)) return e;
-    FwdIn f{x, 0, t, 0, 1, (float)sigma_min, (float)(sigma_max / sigma_min), labels, B, out, B};
+    FwdIn f{x, 0, t, 0, 0.f, 1, (float)sigma_min, (float)(sigma_max / sigma_min), labels, B, out, B};
     int e = run_forward(c, f, s);
     if (c->profiling) prof_collect(c);
     return e;
@@ -1336,7 +1349,7 @@ int rdmi_score(rdmi_ctx* c, const float* x, const float* t, const float* labels,
 static int cf_score_impl(rdmi_ctx* c, const float* x, const float* t, int t_mod, const float* labels, const float* weight,
                          float* out, int B, float smin, float ratio, hipStream_t s) {
     const int E = c->H * c->W * c->arch.channels;
-    FwdIn f{x, B, t, t_mod, 1, smin, ratio, labels, B, c->d_s2, 2 * B};
+    FwdIn f{x, B, t, t_mod, 0.f, 1, smin, ratio, labels, B, c->d_s2, 2 * B};
     if (int e = run_forward(c, f, s)) return e;
     {
         ProfScope ps(c, s, "cfg_combine", 0);
@@ -1414,71 +1427,47 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
     if (int e = maybe_repack(c, flags, s)) return e;
     const int E = c->H * c->W * c->arch.channels;
     const long BE = (long)B * E;
+    const float smin = (float)o->sigma_min, ratio = (float)(o->sigma_max / o->sigma_min);
+    const float gc = g_const(o->sigma_min, o->sigma_max);
+    const unsigned gBE = (unsigned)ceil_div((int)BE, RDMI_THREADS);
+    const uint64_t eoff = (uint64_t)o->seq_offset * (uint64_t)E;
+
     // timesteps = torch.linspace(T=1, eps, N): fp32 step, fma(step, i, start) / fma(-step, N-1-i, end)
-    if (o->N > c->ts_cap) {
-        if (c->d_ts) hipFree(c->d_ts);
-        HIP_OK(hipMalloc((void**)&c->d_ts, (size_t)o->N * sizeof(float)));
-        c->ts_cap = o->N;
-    }
+    std::vector<float> ts((size_t)o->N);
     {
-        std::vector<float> ts((size_t)o->N);
         const float start = 1.0f, end = o->eps;
         const double step = (double)(float)((end - start) / (float)(o->N - 1));
         for (int i = 0; i < o->N; ++i)
             ts[(size_t)i] = (float)(i < o->N / 2 ? (double)start + step * i : (double)end - step * (o->N - 1 - i));
-        HIP_OK(hipMemcpyAsync(c->d_ts, ts.data(), ts.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        HIP_OK(hipStreamSynchronize(s));      // ts is a stack vector
     }
-    HIP_OK(hipMemsetAsync(c->d_state, 0, sizeof(StepState), s));
-    const float smin = (float)o->sigma_min, ratio = (float)(o->sigma_max / o->sigma_min);
-    const float gc = g_const(o->sigma_min, o->sigma_max);
-    const unsigned gBE = (unsigned)ceil_div((int)BE, RDMI_THREADS);
-    const int z_by_draw = noise ? 1 : 0;
-    const float* zsrc = noise ? noise : c->d_z;
-
-    auto score_eval = [&]() -> int {
-        {
-            ProfScope tp(c, s, "fill_time", 0);
-            hipLaunchKernelGGL(fill_time_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, s, c->d_tvec, (const float*)c->d_ts,
-                               (const StepState*)c->d_state, B);
-        }
-        if (o->use_cfg) return cf_score_impl(c, x, c->d_tvec, B, labels, weight, c->d_score, B, smin, ratio, s);
-        FwdIn f{x, 0, c->d_tvec, 0, 1, smin, ratio, labels, B, c->d_score, B};
+    // one score evaluation at the shared time t: the raw network output lands in d_s2 ([2B] with CFG, [B] without)
+    auto net_eval = [&](float t) -> int {
+        FwdIn f{x, o->use_cfg ? B : 0, nullptr, 0, t, 1, smin, ratio, labels, B, c->d_s2, NBm};
         return run_forward(c, f, s);
     };
-    auto draw_noise = [&](int draw_add) {
-        if (noise) return;
-        ProfScope ps(c, s, "philox_normal", 0);
-        hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)ceil_div((int)((BE + 3) / 4), RDMI_THREADS)), dim3(RDMI_THREADS), 0, s,
-                           c->d_z, BE, (uint64_t)o->seed, (uint64_t)o->seq_offset * (uint64_t)E, (const int*)&c->d_state->draw, draw_add);
-    };
-
+    uint32_t draw = 0;
     for (int i = 0; i < o->N - 1; ++i) {
+        const float t = ts[(size_t)i];
         if (o->corrector == 1) {
-            for (int k = 0; k < o->n_steps_each; ++k) {
-                if (int e = score_eval()) return e;
-                draw_noise(0);
-                {
-                    ProfScope ps(c, s, "langevin_update", 0);
-                    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)c->d_score, zsrc,
-                                       (const StepState*)c->d_state, c->d_norms, B, E, z_by_draw);
-                    hipLaunchKernelGGL(langevin_update_kernel, dim3(gBE), dim3(RDMI_THREADS), 64, s, (const float*)x,
-                                       (const float*)c->d_score, zsrc, (const float*)c->d_norms, (const StepState*)c->d_state, x,
-                                       (float*)nullptr, B, E, o->snr, z_by_draw);
-                    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, c->d_state, 0, 1);
-                }
+            for (int k = 0; k < o->n_steps_each; ++k, ++draw) {
+                if (int e = net_eval(t)) return e;
+                ProfScope ps(c, s, "langevin_update", 0);
+                hipLaunchKernelGGL(langevin_prep_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)c->d_s2, weight,
+                                   noise ? noise + (size_t)draw * BE : (const float*)nullptr, c->d_score, c->d_z, c->d_norms, B, E,
+                                   o->use_cfg, (uint64_t)o->seed, eoff, draw);
+                hipLaunchKernelGGL(langevin_update_kernel, dim3(gBE), dim3(RDMI_THREADS), 64, s, (const float*)x,
+                                   (const float*)c->d_score, (const float*)c->d_z, (const float*)c->d_norms, (const StepState*)nullptr, x,
+                                   (float*)nullptr, B, E, o->snr, 0);
             }
         }
-        if (int e = score_eval()) return e;
-        draw_noise(0);
+        if (int e = net_eval(t)) return e;
         {
-            ProfScope ps(c, s, "em_update", 0);
-            hipLaunchKernelGGL(em_update_kernel, dim3(gBE), dim3(RDMI_THREADS), 0, s, (const float*)x, (const float*)c->d_score, zsrc,
-                               (const float*)nullptr, (const float*)c->d_ts, (const StepState*)c->d_state, x, (float*)nullptr, trace,
-                               B, E, o->N, smin, ratio, gc, z_by_draw);
-            if (teacher)
-                hipLaunchKernelGGL(teacher_copy_kernel, dim3(gBE), dim3(RDMI_THREADS), 0, s, x, teacher, (const StepState*)c->d_state, BE);
-            hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, c->d_state, 1, 1);
+            ProfScope ps(c, s, "em_fused", 0);
+            hipLaunchKernelGGL(em_fused_kernel, dim3(gBE), dim3(RDMI_THREADS), 0, s, (const float*)x, (const float*)c->d_s2, weight,
+                               noise ? noise + (size_t)draw * BE : (const float*)nullptr, x, trace ? trace + (size_t)i * BE : (float*)nullptr,
+                               teacher ? teacher + (size_t)i * BE : (const float*)nullptr, B, E, o->N, t, smin, ratio, gc, o->use_cfg,
+                               (uint64_t)o->seed, eoff, draw);
+            ++draw;
         }
         HIP_OK(hipGetLastError());
         if (c->profiling && (i % 16 == 15)) prof_collect(c);

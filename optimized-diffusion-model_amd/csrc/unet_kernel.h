@@ -41,7 +41,8 @@ struct FOp {
     int b_off, b_rs;                              // GATHER source B: b_off < 0 -> global b_g ([n][rows][CB])
     const float* a_g; const float* b_g;
     float* g_out;                                 // STORE / CONV(dst_kind 2) global destination
-    int G, act; float eps;                        // GN
+    int G, act; float eps;                        // GN (src_off >= 0: read from that LDS tensor, write dst: fused copy)
+    int src_off, src_rs;
     const float* gamma; const float* beta;
     int ntap; int tab_off[9];                     // CONV main phases (taps) share lds/rs/nch, weights contiguous
     FPhase main_ph;                               //   (tab_off of main_ph unused; per-tap tables in tab_off[])
@@ -51,7 +52,9 @@ struct FOp {
     int dense_off;                                // >= 0: add dense[n][dense_off + col]
     int resid_off, resid_rs;                      // >= 0: add LDS tensor [row][col]
     float scale;
-    int dst_kind;                                 // 0: LDS [row][col]; 1: LDS transposed [col][row]; 2: global [n][row][col]
+    int dst_kind;                                 // 0: LDS [row][col]; 1: LDS transposed [col][row]; 2: global [n][row][col];
+                                                  // 3: QKV split: cols [0,C) -> dst, [C,2C) -> dst2 (both [row][col]), [2C,3C) -> dst3 transposed
+    int dst2_off, dst3_off, dst3_rs, split_C;
     int q_off, k_off, vt_off, p_off, qk_rs, ps;   // ATTN
     int L, Lpad; float att_scale;
 };
@@ -154,23 +157,26 @@ __device__ __forceinline__ void fop_store(const OpW& w, int n, int tid) {
 // Work-items keep a FIXED float4 channel column (gamma/beta/group loaded once, before the row loop).
 __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid) {
     float* X = lds_f(OPI(w, dst_off));
+    const int src_off = OPI(w, src_off);
+    const float* S = src_off >= 0 ? lds_f(src_off) : X;
+    const int srs = src_off >= 0 ? OPI(w, src_rs) : OPI(w, dst_rs);
     const int G = OPI(w, G), o_C = OPI(w, C), Cg = o_C / G, rs = OPI(w, dst_rs), o_rows = OPI(w, rows), o_act = OPI(w, act);
     const float o_eps = OPF(w, eps);
     const float* o_gamma = OPP(w, const float, gamma); const float* o_beta = OPP(w, const float, beta);
     const int T = UW_THREADS / G;                     // 16 or 32 lanes per group (host-checked power of two <= 64)
     const int g = tid / T, sub = tid - g * T;
     const float inv_cnt = 1.0f / (float)(Cg * o_rows);
-    const float* base = X + g * Cg;
+    const float* base = S + g * Cg;
     float sum = 0.f;
     if ((Cg & 3) == 0) {
         for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; cc += 4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * rs + cc);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs + cc);
                 sum += (q[0] + q[1]) + (q[2] + q[3]);
             }
     } else {
         for (int v = sub; v < o_rows; v += T)
-            for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * rs + cc];
+            for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * srs + cc];
     }
     for (int m = T >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
     const float mean = sum * inv_cnt;
@@ -178,14 +184,14 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid) {
     if ((Cg & 3) == 0) {
         for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; cc += 4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * rs + cc);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs + cc);
                 const float d0 = q[0] - mean, d1 = q[1] - mean, d2 = q[2] - mean, d3 = q[3] - mean;
                 sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
     } else {
         for (int v = sub; v < o_rows; v += T)
             for (int cc = 0; cc < Cg; ++cc) {
-                const float d = base[(size_t)v * rs + cc] - mean;
+                const float d = base[(size_t)v * srs + cc] - mean;
                 sq += d * d;
             }
     }
@@ -204,7 +210,7 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid) {
         for (int j = 0; j < 4; ++j) { const int gg = (c + j) / Cg; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * gm[j]; }
         for (int row = r0; row < o_rows; row += rstep) {
             float* p = X + (size_t)row * rs + c;
-            f32x4 val = *reinterpret_cast<f32x4*>(p);
+            f32x4 val = *reinterpret_cast<const f32x4*>(S + (size_t)row * srs + c);
             for (int j = 0; j < 4; ++j) {
                 const float y = (val[j] - mu[j]) * rstd[j] + bt[j];
                 val[j] = o_act ? silu_f(y) : y;
@@ -310,7 +316,30 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
     if (fine) fine[4] = clock64();
     // ---- epilogue: three destinations, each its own (wave-uniform) branch so LDS stores stay ds_write and global
     //      stores stay global_store (a merged pointer would degrade both to flat_store)
-    if (o_kind == 1) {                        // LDS, transposed [col][row]; all padded rows written (finite)
+    if (o_kind == 3) {                        // fused q/k/v projection: the column tile decides the destination
+        const int sc_ = OPI(w, split_C);
+        const int which = col / sc_, lc = col - which * sc_;          // wave-uniform (16-col tiles never straddle)
+        if (which == 2) {
+            float* dstp = lds_f(OPI(w, dst3_off));
+            const int rs3 = OPI(w, dst3_rs);
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+                f32x4 v = acc[i];
+                for (int r = 0; r < 4; ++r) v[r] = (v[r] + add) * o_scale;
+                *reinterpret_cast<f32x4*>(dstp + lc * rs3 + row0) = v;
+            }
+        } else {
+            float* dstp = lds_f(which == 0 ? o_dst : OPI(w, dst2_off));
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + lc] = (acc[i][r] + add) * o_scale;
+            }
+        }
+    } else if (o_kind == 1) {                 // LDS, transposed [col][row]; all padded rows written (finite)
         float* dstp = lds_f(o_dst);
 #pragma unroll
         for (int i = 0; i < NMT; ++i) {
@@ -360,7 +389,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
 
 __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n, int wave, int lane, long long* fine) {
     const int ntiles = OPI(w, Cout_pad) >> 4, mtiles = OPI(w, mtiles);
-    const int lWN = ntiles >= 8 ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // log2 of waves along N
+    const int lWN = (ntiles >= 8 && (ntiles & 7) == 0) ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // log2 of waves along N
     const int WN = 1 << lWN, WM = UW_WAVES >> lWN, lWM = 3 - lWN;
     const int wn = wave & (WN - 1), wm = wave >> lWN;
     for (int nt = wn; nt < ntiles; nt += WN) {
