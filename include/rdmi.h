@@ -96,6 +96,17 @@ int rdmi_reflect(const float* in, float* out, size_t n, void* stream);
 int rdmi_score_hk(const float* x, const float* x_orig, const float* sigma, float* out, int B, int elems_per_sample,
                   int efs, int refls, float min_cutoff, void* stream);
 
+/* Score-matching loss pieces (RD/losses.py:79-93, get_sde_loss_fn/loss_fn):
+ *   rdmi_perturb : perturbed = reflect(batch + sigma(t) * z)                                   (:81-82)
+ *   rdmi_sm_loss : per_sample[b] = reduce( w_b * (score - score_hk(perturbed, batch, sigma_b))^2 ) with w = sigma^2
+ *                  (g(t)^2 if likelihood_weighting) and reduce = 0.5*sum (mean if reduce_mean)  (:84-92);
+ *                  the batch mean (:93) is left to the caller. */
+int rdmi_perturb(const float* batch, const float* z, const float* t, float* out, int B, int elems_per_sample,
+                 double sigma_min, double sigma_max, void* stream);
+int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch, const float* t, float* per_sample,
+                 int B, int elems_per_sample, double sigma_min, double sigma_max, int likelihood_weighting,
+                 int reduce_mean, void* stream);
+
 /* One reflected Euler-Maruyama update given the score (RD/sampling.py:198-207 with
  * RSDE.sde, RD/sde_lib.py:93-101): x_mean = x + g(t)^2*score/N, x' = x_mean + g(t)*sqrt(1/N)*z,
  * both reflected.  t: device [B]; x_mean_out may be NULL. */

@@ -351,6 +351,63 @@ __global__ __launch_bounds__(RDMI_THREADS) void score_hk_kernel(const float* __r
     }
 }
 
+// Score-matching loss pieces (RD/losses.py:79-93).
+// perturbed = reflect(batch + sigma(t) * z)                                                     (:81-82)
+__global__ __launch_bounds__(RDMI_THREADS) void perturb_kernel(const float* __restrict__ batch, const float* __restrict__ z,
+                                                                const float* __restrict__ t, float* __restrict__ out, int B, int E,
+                                                                float smin, float ratio) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)B * E) return;
+    const float sigma = smin * powf(ratio, t[i / E]);
+    out[i] = reflect_f(batch[i] + sigma * z[i]);
+}
+
+// per_sample[b] = reduce_e( weight_b * (score - score_hk(perturbed, batch, sigma_b))^2 ), one wave per sample:
+//   weight = sigma^2 (or g(t)^2 with likelihood weighting), reduce = 0.5 * sum (or mean)        (:84-92)
+__global__ __launch_bounds__(64) void sm_loss_kernel(const float* __restrict__ score, const float* __restrict__ perturbed,
+                                                     const float* __restrict__ batch, const float* __restrict__ t,
+                                                     float* __restrict__ per_sample, int B, int E, float smin, float ratio,
+                                                     float gconst, int likelihood_weighting, int reduce_mean, int efs, int refls,
+                                                     float cutoff) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float sg = smin * powf(ratio, t[b]);
+    const float th = sg * sg / 2.0f;
+    const float wgt = likelihood_weighting ? (sg * gconst) * (sg * gconst) : sg * sg;
+    const float pi = 3.14159265358979323846f;
+    float acc = 0.f;
+    for (int e = lane; e < E; e += 64) {
+        const long i = (long)b * E + e;
+        const float xv = perturbed[i], ov = batch[i];
+        float num = 0.f, den = 0.f, hk;
+        if (th > cutoff) {
+            const float pi2 = (float)(3.14159265358979323846 * 3.14159265358979323846);
+            for (int k = 1; k <= efs; ++k) {
+                const float kf = (float)k;
+                const float ed = expf((-th * (kf * kf)) * pi2);
+                const float co = cosf((pi * ov) * kf);
+                num += (ed * kf) * (sinf((pi * xv) * kf) * co);
+                den += ed * (cosf((pi * xv) * kf) * co);
+            }
+            hk = ((float)(-2.0 * 3.14159265358979323846) * num) / ((1.0f + 2.0f * den) + 1e-12f);
+        } else {
+            const float fourt = 4.0f * th;
+            for (int half = 0; half < 2; ++half)
+                for (int j = -refls; j <= refls; ++j) {
+                    const float r = (float)(2 * j);
+                    const float xm = (half == 0 ? r + xv : r - xv) - ov;
+                    const float ee = expf(-(xm * xm) / fourt);
+                    num += ((-2.0f * xm / fourt) * ee) * (half == 0 ? 1.0f : -1.0f);
+                    den += ee;
+                }
+            hk = num / (den + 1e-12f);
+        }
+        const float d = score[i] - hk;
+        acc += wgt * (d * d);
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) per_sample[b] = reduce_mean ? acc / (float)E : 0.5f * acc;
+}
+
 // NHWC -> NCHW copy (debug taps and the C=1 boundary is a no-op)
 __global__ __launch_bounds__(RDMI_THREADS) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                                      int NB, int HW, int C) {

@@ -791,6 +791,15 @@ struct FusedBuilder {
         if (src) { o.src_off = src->off; o.src_rs = src->rs; }
         o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
         o.G = std::min(t.C / 4, 32); o.act = act ? 1 : 0; o.eps = 1e-6f;
+        {
+            const int T = UW_THREADS / o.G, c4n = t.C / 4;
+            o.logT = T == 32 ? 5 : (T == 16 ? 4 : (T == 64 ? 6 : 3));
+            o.Cg = t.C / o.G;
+            o.magic_c4n = (65536 + c4n - 1) / c4n; o.magic_Cg = (65536 + o.Cg - 1) / o.Cg;
+            o.inv_cnt = 1.0f / (float)(o.Cg * t.rows());
+            if ((1 << o.logT) != T) fail_("GroupNorm lanes-per-group not a power of two");
+            if (ceil_div(t.rows(), T) > 6 || o.Cg > 8) fail_("GroupNorm group too large for the register-resident statistics");
+        }
         if (t.C % o.G != 0 || UW_THREADS % o.G != 0 || UW_THREADS / o.G > 64) fail_("GroupNorm shape C=" + std::to_string(t.C));
         const int idx = emit(o);
         patch_param(idx, F_GAMMA, pre + ".weight"); patch_param(idx, F_BETA, pre + ".bias");
@@ -1388,9 +1397,29 @@ int rdmi_score_hk(const float* x, const float* x_orig, const float* sigma, float
     return 0;
 }
 
+
 static float g_const(double smin, double smax) {
     // torch.sqrt(torch.tensor(2 * (np.log(sigma_max) - np.log(sigma_min)), dtype=float32))   RD/sde_lib.py:138-139
     return sqrtf((float)(2.0 * (std::log(smax) - std::log(smin))));
+}
+
+int rdmi_perturb(const float* batch, const float* z, const float* t, float* out, int B, int E, double sigma_min,
+                 double sigma_max, void* stream) {
+    if (!batch || !z || !t || !out) return fail("null argument");
+    hipLaunchKernelGGL(perturb_kernel, dim3((unsigned)ceil_div(B * E, RDMI_THREADS)), dim3(RDMI_THREADS), 0, (hipStream_t)stream, batch,
+                       z, t, out, B, E, (float)sigma_min, (float)(sigma_max / sigma_min));
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch, const float* t, float* per_sample, int B,
+                 int E, double sigma_min, double sigma_max, int likelihood_weighting, int reduce_mean, void* stream) {
+    if (!score || !perturbed || !batch || !t || !per_sample) return fail("null argument");
+    hipLaunchKernelGGL(sm_loss_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, score, perturbed, batch, t, per_sample, B, E,
+                       (float)sigma_min, (float)(sigma_max / sigma_min), g_const(sigma_min, sigma_max), likelihood_weighting, reduce_mean,
+                       20, 10, 1e-2f);
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int rdmi_em_update(const float* x, const float* score, const float* z, const float* t, float* x_out, float* x_mean_out,

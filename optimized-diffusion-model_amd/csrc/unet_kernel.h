@@ -43,6 +43,7 @@ struct FOp {
     float* g_out;                                 // STORE / CONV(dst_kind 2) global destination
     int G, act; float eps;                        // GN (src_off >= 0: read from that LDS tensor, write dst: fused copy)
     int src_off, src_rs;
+    int logT, Cg, magic_c4n, magic_Cg; float inv_cnt;   // GN: host-precomputed (no integer/float divisions on the device)
     const float* gamma; const float* beta;
     int ntap; int tab_off[9];                     // CONV main phases (taps) share lds/rs/nch, weights contiguous
     FPhase main_ph;                               //   (tab_off of main_ph unused; per-tap tables in tab_off[])
@@ -153,71 +154,104 @@ __device__ __forceinline__ void fop_store(const OpW& w, int n, int tid) {
     }
 }
 
-// In-place GroupNorm (two-pass statistics, T lanes per group) + affine (+ SiLU).  stat: LDS scratch [2*G].
-// Work-items keep a FIXED float4 channel column (gamma/beta/group loaded once, before the row loop).
-__device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid) {
+// xor-shuffle sum over groups of T lanes with COMPILE-TIME masks (DPP / permlane forms instead of ds_bpermute)
+template <int T>
+__device__ __forceinline__ float group_sum(float v) {
+    if (T >= 64) v += __shfl_xor(v, 32);
+    if (T >= 32) v += __shfl_xor(v, 16);
+    if (T >= 16) v += __shfl_xor(v, 8);
+    if (T >= 8) v += __shfl_xor(v, 4);
+    if (T >= 4) v += __shfl_xor(v, 2);
+    if (T >= 2) v += __shfl_xor(v, 1);
+    return v;
+}
+__device__ __forceinline__ float group_sum_rt(float v, int logT) {
+    switch (logT) {
+        case 6: return group_sum<64>(v);
+        case 5: return group_sum<32>(v);
+        case 4: return group_sum<16>(v);
+        default: return group_sum<8>(v);
+    }
+}
+
+// GroupNorm (+SiLU) of an LDS tensor, in place or from a source tensor (fused copy).  Two-pass statistics with the
+// group's values held in REGISTERS between the passes (one LDS read per element), T lanes per group reduced by
+// xor-shuffles; the affine parameters of this work-item's fixed channel quad are prefetched by the caller one op
+// ahead (pgm/pbt) so their global latency never sits on the op-transition path.
+__device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4 pgm, f32x4 pbt) {
     float* X = lds_f(OPI(w, dst_off));
     const int src_off = OPI(w, src_off);
     const float* S = src_off >= 0 ? lds_f(src_off) : X;
     const int srs = src_off >= 0 ? OPI(w, src_rs) : OPI(w, dst_rs);
-    const int G = OPI(w, G), o_C = OPI(w, C), Cg = o_C / G, rs = OPI(w, dst_rs), o_rows = OPI(w, rows), o_act = OPI(w, act);
+    const int o_C = OPI(w, C), Cg = OPI(w, Cg), rs = OPI(w, dst_rs), o_rows = OPI(w, rows), o_act = OPI(w, act);
     const float o_eps = OPF(w, eps);
-    const float* o_gamma = OPP(w, const float, gamma); const float* o_beta = OPP(w, const float, beta);
-    const int T = UW_THREADS / G;                     // 16 or 32 lanes per group (host-checked power of two <= 64)
-    const int g = tid / T, sub = tid - g * T;
-    const float inv_cnt = 1.0f / (float)(Cg * o_rows);
+    const int logT = OPI(w, logT), T = 1 << logT;     // 16 or 32 lanes per group
+    const int g = tid >> logT, sub = tid & (T - 1);
+    const float inv_cnt = OPF(w, inv_cnt);
+    const int mg_c4n = OPI(w, magic_c4n), mg_Cg = OPI(w, magic_Cg);
     const float* base = S + g * Cg;
+    // this lane's share of the group: rows sub, sub+T, ... (<= 6 rows for 96 pixels at T = 16), Cg <= 8 channels
+    constexpr int MAXR = 6;
+    f32x4 v0[MAXR], v1[MAXR];
     float sum = 0.f;
-    if ((Cg & 3) == 0) {
-        for (int v = sub; v < o_rows; v += T)
-            for (int cc = 0; cc < Cg; cc += 4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs + cc);
-                sum += (q[0] + q[1]) + (q[2] + q[3]);
+    const int q4 = (Cg + 3) >> 2;                     // float4 per row of the group: 1 (Cg=4), 2 (Cg=6: 4+2, Cg=8)
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+        const int v = sub + k * T;
+        v0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (v < o_rows) {
+            if ((Cg & 3) == 0) {
+                v0[k] = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs);
+                if (q4 > 1) v1[k] = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs + 4);
+            } else {                                   // Cg = 6 (C = 192): groups start at 8-byte, not 16-byte, boundaries
+                for (int cc = 0; cc < 4; ++cc) v0[k][cc] = base[(size_t)v * srs + cc];
+                for (int cc = 4; cc < Cg; ++cc) v1[k][cc - 4] = base[(size_t)v * srs + cc];
             }
-    } else {
-        for (int v = sub; v < o_rows; v += T)
-            for (int cc = 0; cc < Cg; ++cc) sum += base[(size_t)v * srs + cc];
+            sum += (v0[k][0] + v0[k][1]) + (v0[k][2] + v0[k][3]) + (v1[k][0] + v1[k][1]) + (v1[k][2] + v1[k][3]);
+        }
     }
-    for (int m = T >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    sum = group_sum_rt(sum, logT);
     const float mean = sum * inv_cnt;
     float sq = 0.f;
-    if ((Cg & 3) == 0) {
-        for (int v = sub; v < o_rows; v += T)
-            for (int cc = 0; cc < Cg; cc += 4) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs + cc);
-                const float d0 = q[0] - mean, d1 = q[1] - mean, d2 = q[2] - mean, d3 = q[3] - mean;
-                sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-    } else {
-        for (int v = sub; v < o_rows; v += T)
-            for (int cc = 0; cc < Cg; ++cc) {
-                const float d = base[(size_t)v * srs + cc] - mean;
-                sq += d * d;
-            }
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+        const int v = sub + k * T;
+        if (v < o_rows) {
+            for (int cc = 0; cc < 4; ++cc) { const float d = v0[k][cc] - mean; sq += d * d; }
+            for (int cc = 4; cc < Cg; ++cc) { const float d = v1[k][cc - 4] - mean; sq += d * d; }
+        }
     }
-    for (int m = T >> 1; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    sq = group_sum_rt(sq, logT);
     if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
     // fixed channel quad per work-item: rows advance by rstep; work-items beyond rstep*c4n idle (C = 192)
     const int c4n = o_C >> 2;
-    const int rstep = UW_THREADS / c4n;
-    const int r0 = tid / c4n, c = (tid - r0 * c4n) << 2;
+    const int rstep = (UW_THREADS * mg_c4n) >> 16;      // floor(512 / c4n)
+    const int r0 = (tid * mg_c4n) >> 16, c = (tid - r0 * c4n) << 2;
     const bool active = r0 < rstep;
-    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
-    if (active) { gm = ldg4(o_gamma + c); bt = ldg4(o_beta + c); }
     __syncthreads();
     if (active) {
         f32x4 mu, rstd;
-        for (int j = 0; j < 4; ++j) { const int gg = (c + j) / Cg; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * gm[j]; }
+        for (int j = 0; j < 4; ++j) { const int gg = ((c + j) * mg_Cg) >> 16; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
         for (int row = r0; row < o_rows; row += rstep) {
             float* p = X + (size_t)row * rs + c;
             f32x4 val = *reinterpret_cast<const f32x4*>(S + (size_t)row * srs + c);
             for (int j = 0; j < 4; ++j) {
-                const float y = (val[j] - mu[j]) * rstd[j] + bt[j];
+                const float y = (val[j] - mu[j]) * rstd[j] + pbt[j];
                 val[j] = o_act ? silu_f(y) : y;
             }
             *reinterpret_cast<f32x4*>(p) = val;
         }
     }
+}
+
+// Affine parameters of the NEXT op when it is a GroupNorm: this work-item's fixed channel quad (see fop_gn).
+__device__ __forceinline__ void gn_prefetch(const OpW& nx, int tid, f32x4& pgm, f32x4& pbt) {
+    if (OPI(nx, kind) != FOP_GN) return;
+    const int c4n = OPI(nx, C) >> 2, mg = OPI(nx, magic_c4n);
+    const int r0 = (tid * mg) >> 16, c = (tid - r0 * c4n) << 2;
+    const float* gp = OPP(nx, const float, gamma);      // field reads are wave-uniform: keep them outside divergent code
+    const float* bp = OPP(nx, const float, beta);
+    if (r0 < ((UW_THREADS * mg) >> 16)) { pgm = ldg4(gp + c); pbt = ldg4(bp + c); }
 }
 
 // A-row byte offset for one table entry (-1 -> the shared zero row)
@@ -514,24 +548,30 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     }
     float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
     if (u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
+    // descriptors are kept TWO ops ahead (cur, nxt resident; the load for pc+2 is in flight) so that small operands
+    // of the next op can be prefetched while the current one runs
     OpW cur = opw_load(u.prog, lane);
+    OpW nxt = opw_load(u.prog + (u.nops > 1 ? 1 : 0), lane);
+    f32x4 pgm = {1.f, 1.f, 1.f, 1.f}, pbt = {0.f, 0.f, 0.f, 0.f};
+    gn_prefetch(cur, tid, pgm, pbt);
     for (int pc = 0; pc < u.nops; ++pc) {
-        // next op's descriptor words: issued now, consumed next iteration (latency hides under this op)
-        const OpW nxt = opw_load(u.prog + (pc + 1 < u.nops ? pc + 1 : pc), lane);
+        const OpW nn = opw_load(u.prog + (pc + 2 < u.nops ? pc + 2 : u.nops - 1), lane);
         long long* fine = (u.stamps && n == 0 && tid == 0) ? u.stamps + 1024 + pc * 8 : nullptr;
         const int kind = OPI(cur, kind);
         if (fine) fine[2] = clock64();
+        f32x4 ngm = pgm, nbt = pbt;
+        if (pc + 1 < u.nops) gn_prefetch(nxt, tid, ngm, nbt);
         if (fine) fine[3] = clock64();
         switch (kind) {
             case FOP_GATHER: fop_gather(cur, u, n, tid); break;
             case FOP_STORE: fop_store(cur, n, tid); break;
-            case FOP_GN: fop_gn(cur, stat, tid); break;
+            case FOP_GN: fop_gn(cur, stat, tid, pgm, pbt); break;
             case FOP_CONV: fop_conv(cur, u, n, wave, lane, fine); break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             default: break;
         }
         __syncthreads();
         if (u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
-        cur = nxt;
+        cur = nxt; nxt = nn; pgm = ngm; pbt = nbt;
     }
 }

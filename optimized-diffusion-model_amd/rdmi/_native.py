@@ -45,6 +45,8 @@ _PROTOS = {
     'rdmi_cf_score': ([C.c_void_p, _F, _F, _F, _F, _F, C.c_int, C.c_double, C.c_double, C.c_uint, C.c_void_p], C.c_int),
     'rdmi_reflect': ([_F, _F, C.c_size_t, C.c_void_p], C.c_int),
     'rdmi_score_hk': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
+    'rdmi_perturb': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
+    'rdmi_sm_loss': ([_F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p], C.c_int),
     'rdmi_em_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
     'rdmi_langevin_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_pc_sample': ([C.c_void_p, _F, _F, _F, _F, _F, _F, C.c_int, C.POINTER(PcOpts), C.c_uint, C.c_void_p], C.c_int),
@@ -234,6 +236,25 @@ def score_hk(x, x_orig, sigma, efs, refls, min_cutoff):
     check(lib().rdmi_score_hk(ptr(x), ptr(x_orig.contiguous()), ptr(sigma.contiguous().float()), ptr(out), B, x.numel() // B,
                               efs, refls, min_cutoff, stream_of(x)))
     return out
+
+
+def perturb(batch, z, t, smin, smax):
+    require_device(batch)
+    out = torch.empty_like(batch)
+    B = batch.shape[0]
+    check(lib().rdmi_perturb(ptr(batch.contiguous()), ptr(z.contiguous()), ptr(t.contiguous().float()), ptr(out), B,
+                             batch.numel() // B, smin, smax, stream_of(batch)))
+    return out
+
+
+def sm_loss(score, perturbed, batch, t, smin, smax, likelihood_weighting, reduce_mean):
+    require_device(batch)
+    B = batch.shape[0]
+    per = torch.empty(B, dtype=torch.float32, device=batch.device)
+    check(lib().rdmi_sm_loss(ptr(score.contiguous()), ptr(perturbed.contiguous()), ptr(batch.contiguous()),
+                             ptr(t.contiguous().float()), ptr(per), B, batch.numel() // B, smin, smax,
+                             int(bool(likelihood_weighting)), int(bool(reduce_mean)), stream_of(batch)))
+    return per
 
 
 def em_update(x, score, z, t, N, smin, smax):

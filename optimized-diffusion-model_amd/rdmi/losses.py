@@ -1,0 +1,99 @@
+"""Loss, optimizer and step functions.
+
+Host mirror of Reflected-Diffusion/losses.py ("RD/losses.py"): get_optimizer, optimization_manager,
+get_sde_loss_fn, get_step_fn with the reference's signatures and `state` dict contract
+(state = dict(optimizer, model, ema, step, scaler), RD/run_train.py:224-225).
+
+What runs where (round 1):
+  * the loss arithmetic -- perturbation + reflection, the reflected-heat-kernel target (cube.score_hk) and the
+    weighted squared error reduction -- is two HIP kernels (rdmi_perturb, rdmi_sm_loss);
+  * the network forward is the fused HIP U-Net; this covers the EVALUATION step end to end (EMA swap, no_grad);
+  * the TRAINING step needs the network backward, which is not built yet: step_fn(train=True) raises
+    NotImplementedError instead of silently falling back to a torch graph ("Not built yet").
+The reference's per-call NaN hooks (RD/losses.py:95-104) are deliberately not reproduced: they leak one hook per
+parameter per call and slow training from 0.5 s to 38 s per step.
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import _native
+from .models import utils as mutils
+
+
+def get_optimizer(config, params):
+    """RD/losses.py:12-23."""
+    o = config.optim
+    if o.optimizer == 'Adam':
+        return optim.Adam(params, lr=o.lr, betas=(o.beta1, o.beta2), eps=o.eps, weight_decay=o.weight_decay)
+    if o.optimizer == 'AdamW':
+        return optim.AdamW(params, lr=o.lr, betas=(o.beta1, o.beta2), eps=o.eps, weight_decay=o.weight_decay)
+    raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
+
+
+def optimization_manager(config):
+    """RD/losses.py:26-49: linear warm-up, gradient clipping (disabled if negative), optional GradScaler."""
+
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup,
+                    grad_clip=config.optim.grad_clip, scaler=None):
+        if scaler is not None:
+            scaler.unscale_(optimizer)
+        if warmup > 0:
+            for g in optimizer.param_groups:
+                g['lr'] = lr * np.minimum(step / warmup, 1.0)
+        if grad_clip >= 0:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
+        if scaler is None:
+            optimizer.step()
+        else:
+            scaler.step(optimizer)
+            scaler.update()
+
+    return optimize_fn
+
+
+def get_sde_loss_fn(sde, train, reduce_mean=True, likelihood_weighting=True, eps=1e-5):
+    """RD/losses.py:52-107.  loss_fn(model, batch, class_labels=None) -> scalar tensor."""
+
+    def loss_fn(model, batch, class_labels=None):
+        if train:
+            raise NotImplementedError(
+                'training loss: the NCSN++ backward pass is not built in librdmi yet (round 1 covers sampling and the '
+                'evaluation loss); refusing to fall back to a torch autograd graph')
+        score_fn = mutils.get_score_fn(sde, model, train=False)
+        t = torch.rand(batch.shape[0], device=batch.device) * (sde.T - eps) + eps
+        z = torch.randn_like(batch)
+        smin, smax = float(sde.sigma_min), float(sde.sigma_max)
+        perturbed = _native.perturb(batch.float(), z, t, smin, smax)                  # reflect(mean + std z)
+        with torch.no_grad():
+            score = score_fn(perturbed, t, class_labels=class_labels)
+        per = _native.sm_loss(score, perturbed, batch.float(), t, smin, smax, likelihood_weighting, reduce_mean)
+        return torch.mean(per)
+
+    return loss_fn
+
+
+def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, likelihood_weighting=False):
+    """RD/losses.py:110-160.  step_fn(state, batch, class_labels=None) -> loss."""
+    loss_fn = get_sde_loss_fn(sde, train, reduce_mean=reduce_mean, likelihood_weighting=likelihood_weighting)
+
+    def step_fn(state, batch, class_labels=None):
+        model = state['model']
+        if train:
+            optimizer = state['optimizer']
+            optimizer.zero_grad()
+            loss = loss_fn(model, batch, class_labels=class_labels)       # raises: backward not built (see module doc)
+            loss.backward()
+            optimize_fn(optimizer, model.parameters(), step=state['step'], scaler=state['scaler'])
+            state['step'] += 1
+            state['ema'].update(model.parameters())
+            return loss
+        with torch.no_grad():
+            ema = state['ema']
+            ema.store(model.parameters())
+            ema.copy_to(model.parameters())
+            loss = loss_fn(model, batch, class_labels=class_labels)
+            ema.restore(model.parameters())
+        return loss
+
+    return step_fn

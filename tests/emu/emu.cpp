@@ -12,7 +12,7 @@
 namespace emu {
 
 enum State { READY, WAIT_BLOCK, WAIT_WAVE, DONE };
-constexpr size_t STACK = 96 * 1024;
+constexpr size_t STACK = 256 * 1024;
 constexpr int SLOT = 32;
 
 struct Wave {

@@ -156,3 +156,36 @@ def test_param_rebinding_is_seen(env):
         ema.restore(model.parameters())
         d = fn(x, t, class_labels=lab)
     assert not torch.allclose(a, b) and torch.equal(a, c) and torch.equal(b, d)
+
+
+def _eval_loss(ge, dev, golden_npz, model):
+    from rdmi import losses, sde_lib
+    from rdmi.models.ema import ExponentialMovingAverage
+    g = golden_npz
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    state = dict(optimizer=None, model=model, ema=ExponentialMovingAverage(model.parameters(), 0.999), step=0, scaler=None)
+    ev = losses.get_step_fn(sde, train=False, optimize_fn=None, reduce_mean=False, likelihood_weighting=False)
+    tv, zv = torch.from_numpy(g['step0.t']).to(dev), torch.from_numpy(g['step0.z']).to(dev)
+    _r, _n = torch.rand, torch.randn_like
+    torch.rand = lambda *a, **k: ((tv - 1e-5) / (1 - 1e-5)).clone()
+    torch.randn_like = lambda x, **k: zv.clone()
+    try:
+        return float(ev(state, torch.from_numpy(g['batch']).to(dev), class_labels=torch.from_numpy(g['labels']).to(dev)))
+    finally:
+        torch.rand, torch.randn_like = _r, _n
+
+
+def test_eval_loss_step_matches_reference(env, golden):
+    """losses.get_step_fn(train=False): perturb + reflect + score_hk target + weighted SSE (HIP kernels) with the
+    reference's recorded (t, z): the reference's own loss value for the same weights (dropout and label drop off)."""
+    g = golden('train_step.npz')
+    loss = _eval_loss(env['ge'], 'cpu', g, env['model'])
+    np.testing.assert_allclose(loss, float(g['step0.loss']), rtol=2e-5)
+
+
+def test_training_step_refuses_instead_of_falling_back(env):
+    from rdmi import losses, sde_lib
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    fn = losses.get_sde_loss_fn(sde, train=True, reduce_mean=False, likelihood_weighting=False)
+    with pytest.raises(NotImplementedError, match='backward'):
+        fn(env['model'], torch.rand(2, 1, 9, 9), class_labels=torch.rand(2, 1))

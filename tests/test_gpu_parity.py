@@ -273,3 +273,25 @@ def test_large_batch_many_workgroups(env):
     ref = O.score_fn(params, O.RVESDE(0.01, 5, N=1000), x.numpy()[idx], t.numpy()[idx], lab.numpy()[idx])
     np.testing.assert_allclose(s[idx], ref, rtol=0, atol=2e-4)
     assert np.isfinite(s).all()
+
+
+def test_eval_loss_step_matches_reference(env, golden):
+    """The evaluation step of losses.get_step_fn on the GPU against the reference's recorded loss value."""
+    from tests.test_emu_parity import _eval_loss
+    g = golden('train_step.npz')
+    loss = _eval_loss(env['ge'], env['dev'], g, env['model'])
+    np.testing.assert_allclose(loss, float(g['step0.loss']), rtol=1e-4)
+    # likelihood weighting / reduce_mean variants against the oracle
+    from oracle import rd_oracle as O
+    from rdmi import _native
+    dev = env['dev']
+    t = T(g['step0.t'], dev); z = T(g['step0.z'], dev); batch = T(g['batch'], dev)
+    pert = _native.perturb(batch, z, t, 0.01, 5.0)
+    o = O.RVESDE(0.01, 5, N=1000)
+    ref_p = O.reflect(g['batch'] + o.sigma(g['step0.t'])[:, None, None, None] * g['step0.z'])
+    np.testing.assert_allclose(pert.cpu().numpy(), ref_p, rtol=0, atol=2e-6)
+    score = torch.randn_like(batch)
+    per = _native.sm_loss(score, pert, batch, t, 0.01, 5.0, True, True).cpu().numpy()
+    tgt = O.score_hk(ref_p, g['batch'], o.sigma(g['step0.t']))
+    ref = ((o.g(g['step0.t']) ** 2)[:, None, None, None] * (score.cpu().numpy() - tgt) ** 2).reshape(8, -1).mean(-1)
+    np.testing.assert_allclose(per, ref, rtol=2e-3)
