@@ -1,0 +1,5 @@
+"""Drop-in module: put optimized-diffusion-model_amd/dropin (and its parent) on sys.path in place of the reference's
+Reflected-Diffusion/ directory and `import losses` resolves to the MI355X-native implementation (rdmi.losses)."""
+from rdmi.losses import *  # noqa: F401,F403
+from rdmi import losses as _impl
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith('__')})
