@@ -33,6 +33,7 @@ PEAK_HBM_GBPS = 8000.0
 GFLOP_PER_FORWARD = 0.220438528        # 110 219 264 MAC per sample-forward at 9x9
 ACT_BYTES_PER_FORWARD = 4440464        # layer-granular activation bytes per sample-forward
 WEIGHT_BYTES = 25019652
+PMC_TRAFFIC_BYTES_UNET_B128 = (2 * 98143 + 15576) * 1024   # profiles/r01_pmc_hbm_traffic_unet_wg_kernel.md
 
 
 def main():
@@ -61,7 +62,11 @@ def main():
     dev = torch.device(f'cuda:{local}')
 
     import __graft_entry__ as ge
-    ge.build()
+    if local == 0:
+        ge.build()                    # one rank per node compiles (no-op when librdmi.so is fresh) ...
+    if world > 1:
+        dist.barrier()
+    ge.build()                        # ... everyone loads
     from rdmi import sampling, sde_lib
     from rdmi.parallel import sharded_sampling_fn
 
@@ -147,8 +152,12 @@ def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, 
                              'share': p['ms'] / total_ms, 'tflops': (p['flops'] / (p['ms'] * 1e-3) / 1e12) if p['flops'] else None}
                for p in sorted(prof, key=lambda p: -p['ms'])}
     hbm_bytes_per_traj = fwd_per_traj * ACT_BYTES_PER_FORWARD + (fwd_per_traj / 2) * WEIGHT_BYTES / shape[0]
+    # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    # they cannot be collected from inside this process): profiles/r01_pmc_hbm_traffic_unet_wg_kernel.md, B=128 shape only.
+    traffic = PMC_TRAFFIC_BYTES_UNET_B128 if (dom['kernel'] == 'unet_wg_kernel' and shape[0] == 128 and shape[2] * shape[3] == 81) else None
     return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+            'traffic_note': 'bytes/launch from rocprofv3 PMC passes of this command, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; see profiles/',
             'avg_launch_us': 1e3 * dom['ms'] / max(dom['launches'], 1), 'launches': dom['launches'], 'plan': plan,
             'whole_path_frac_of_fp32_peak': traj_per_s_per_gpu * fwd_per_traj * GFLOP_PER_FORWARD / 1e3 / PEAK_FP32_MFMA_TFLOPS,
             'whole_path_layer_granular_hbm_frac': traj_per_s_per_gpu * hbm_bytes_per_traj / 1e9 / PEAK_HBM_GBPS,
