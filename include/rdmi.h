@@ -104,8 +104,19 @@ int rdmi_score_hk(const float* x, const float* x_orig, const float* sigma, float
 int rdmi_perturb(const float* batch, const float* z, const float* t, float* out, int B, int elems_per_sample,
                  double sigma_min, double sigma_max, void* stream);
 int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch, const float* t, float* per_sample,
-                 int B, int elems_per_sample, double sigma_min, double sigma_max, int likelihood_weighting,
-                 int reduce_mean, void* stream);
+                 float* dscore /* NULL or [B,E]: d per_sample / d score for the backward */, int B, int elems_per_sample,
+                 double sigma_min, double sigma_max, int likelihood_weighting, int reduce_mean, void* stream);
+
+/* Training step (RD/losses.py:141-149): train-mode forward of NCSNpp (Dropout_0 with probability dropout_p on the input of
+ * every Conv_1, RD/models/layerspp.py:204; label drop is the caller's, RD/models/ncsnpp.py:242-246) keeping every
+ * activation, and the backward pass.  rdmi_enable_training switches the context to the layer plan with per-tensor storage
+ * and allocates gradient workspace (use a dedicated context for training).  rdmi_backward writes d loss / d parameter for
+ * ALL parameters into grads_flat in the reference's parameter order (offset of parameter i = sum of numel of 0..i-1;
+ * the frozen time_embed.W slice stays zero); `x` is the network input of the forward call. */
+int rdmi_enable_training(rdmi_ctx* ctx);
+int rdmi_train_forward(rdmi_ctx* ctx, const float* x, const float* sigma, const float* labels, float* out, int B,
+                       float dropout_p, uint64_t seed, void* stream);
+int rdmi_backward(rdmi_ctx* ctx, const float* grad_out, float* grads_flat, size_t grads_numel, const float* x, void* stream);
 
 /* One reflected Euler-Maruyama update given the score (RD/sampling.py:198-207 with
  * RSDE.sde, RD/sde_lib.py:93-101): x_mean = x + g(t)^2*score/N, x' = x_mean + g(t)*sqrt(1/N)*z,

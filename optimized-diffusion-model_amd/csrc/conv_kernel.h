@@ -21,6 +21,16 @@
 //   * the NIN shortcut is folded in as one more K phase over the raw block input (second LDS region).
 #pragma once
 #include "common.h"
+#include "misc_kernels.h"
+
+// dropout keep-mask for element (op, n, pixel, channel): Philox keyed by the step seed; the backward recomputes it
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t op, uint64_t elem, float p) {
+    if (p <= 0.f) return 1.f;
+    uint32_t c[4] = {(uint32_t)(elem >> 2), (uint32_t)(elem >> 34), op, 0x44524f50u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u = ((float)c[elem & 3] + 0.5f) * 2.3283064365386963e-10f;
+    return u < p ? 0.f : 1.0f / (1.0f - p);
+}
 
 struct ConvArgs {
     // virtual conv input = concat_c( gather(srcA, mapA) , srcB ), optionally GroupNorm+SiLU'd
@@ -47,6 +57,7 @@ struct ConvArgs {
     int dense_stride, dense_off;
     float out_scale, eps;
     int S, BN, Mpad;
+    float drop_p; uint64_t drop_seed; uint32_t op_id;   // train mode: dropout after GN+SiLU (Dropout_0, RD/models/layerspp.py:204)
     int dbg;                      // ablation switches for profiling builds (0 in production): 1 = skip GEMM, 2 = skip GN
 };
 
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
                 if (left == 0) { ++gg; left = Cg; }
                 const float mu = stat[2 * (ss * G + gg)], rstd = stat[2 * (ss * G + gg) + 1];
                 val[j] = silu_f((val[j] - mu) * rstd * gm[j] + bt[j]);
+                if (a.drop_p > 0.f) val[j] *= dropout_scale(a.drop_seed, a.op_id, ((uint64_t)(n0 + ss) * a.HWv + v) * a.Cv + c + j, a.drop_p);
                 --left;
             }
             *reinterpret_cast<f32x4*>(p) = val;

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void perturb_kernel(const float* __re
 //   weight = sigma^2 (or g(t)^2 with likelihood weighting), reduce = 0.5 * sum (or mean)        (:84-92)
 __global__ __launch_bounds__(64) void sm_loss_kernel(const float* __restrict__ score, const float* __restrict__ perturbed,
                                                      const float* __restrict__ batch, const float* __restrict__ t,
-                                                     float* __restrict__ per_sample, int B, int E, float smin, float ratio,
+                                                     float* __restrict__ per_sample, float* __restrict__ dscore, int B, int E, float smin, float ratio,
                                                      float gconst, int likelihood_weighting, int reduce_mean, int efs, int refls,
                                                      float cutoff) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64) void sm_loss_kernel(const float* __restrict__ s
         }
         const float d = score[i] - hk;
         acc += wgt * (d * d);
+        if (dscore) dscore[i] = reduce_mean ? 2.0f * wgt * d / (float)E : wgt * d;     // d per_sample[b] / d score[i]
     }
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
     if (lane == 0) per_sample[b] = reduce_mean ? acc / (float)E : 0.5f * acc;

@@ -20,6 +20,7 @@
 #include "conv_kernel.h"
 #include "misc_kernels.h"
 #include "unet_kernel.h"
+#include "bwd_kernels.h"
 
 namespace {
 
@@ -59,6 +60,27 @@ struct Tensor {
     size_t per_sample() const { return (size_t)C * H * W; }
 };
 
+// description of one fused conv launch of the layer plan (kept per op: the backward plan is derived from it)
+struct ConvSpec {
+    std::string name;
+    int tA = -1, tB = -1;           // sources (tA == -2: caller's x)
+    int CA = 0, CB = 0;
+    int Ha = 0, Wa = 0;             // source-A dims
+    int Hv = 0, Wv = 0;             // virtual input dims
+    std::string gn;                 // GroupNorm param prefix ("" = none)
+    std::string conv;               // conv param prefix
+    int stride = 1, pad_lo = 1;
+    int Ho = 0, Wo = 0, Cout = 0;
+    // shortcut
+    int tScA = -1, tScB = -1, CscA = 0, CscB = 0, Hsa = 0, Wsa = 0;
+    std::string nin;
+    int dense_off = -1;
+    int tRes = -1;
+    float scale = 1.f;
+    bool to_output = false;
+    bool dropout = false;
+};
+
 enum OpKind { OP_CONV, OP_ATTN };
 
 struct Op {
@@ -80,6 +102,9 @@ struct Op {
     // packed weight locations (floats into the weight arena)
     size_t w_off = 0, wsc_off = 0, w3_off = 0, bqkv_off = 0;
     std::string p_gamma, p_beta, p_bias, p_bias_sc, p_b3;
+    ConvSpec spec;               // OP_CONV: what was asked for
+    int attn_C = 0, attn_H = 0, attn_W = 0;
+    bool dropout = false;        // train mode applies Dropout_0 to this op's activated input (Conv_1 of a resblock)
 };
 
 struct ProfEntry { std::string name; double ms = 0; long launches = 0; double flops = 0; };
@@ -298,25 +323,6 @@ struct Builder {
         return m;
     }
 
-    struct ConvSpec {
-        std::string name;
-        int tA = -1, tB = -1;           // sources (tA == -2: caller's x)
-        int CA = 0, CB = 0;
-        int Ha = 0, Wa = 0;             // source-A dims
-        int Hv = 0, Wv = 0;             // virtual input dims
-        std::string gn;                 // GroupNorm param prefix ("" = none)
-        std::string conv;               // conv param prefix
-        int stride = 1, pad_lo = 1;
-        int Ho = 0, Wo = 0, Cout = 0;
-        // shortcut
-        int tScA = -1, tScB = -1, CscA = 0, CscB = 0, Hsa = 0, Wsa = 0;
-        std::string nin;
-        int dense_off = -1;
-        int tRes = -1;
-        float scale = 1.f;
-        bool to_output = false;
-    };
-
     int add_conv(const ConvSpec& s, int* err) {
         Op op;
         op.kind = OP_CONV;
@@ -337,6 +343,8 @@ struct Builder {
         op.a_is_input = (s.tA == -2);
         op.out_is_output = s.to_output;
         op.use_dense = s.dense_off >= 0;
+        op.spec = s;
+        op.dropout = s.dropout;
         // tile configuration
         if (a.Cout_pad < 32) { op.cfg = 3; a.S = 1; a.BN = 16; }                   // <4,1,1,2,1>
         else if (a.HWo >= 40) { op.cfg = 0; a.S = 1; a.BN = 64; }                  // <1,4,1,6,1>
@@ -420,6 +428,7 @@ struct Builder {
         op.p_b3 = name + ".NIN_3.b";
         op.p_gamma = name + ".GroupNorm_0.weight"; op.p_beta = name + ".GroupNorm_0.bias";
         op.flops_per_sample = 2.0 * (4.0 * a.L * C * C + 2.0 * a.L * a.L * C);
+        op.attn_C = C; op.attn_H = H; op.attn_W = W;
         use(tin);
         const int out = new_tensor(name, C, H, W);
         op.out_tensor = out;
@@ -431,19 +440,20 @@ struct Builder {
 // one ResnetBlockDDPMpp = two fused conv launches
 int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, int CB, int Ha, int Wa, int H, int W,
                  int cout, int dense_off, int* err) {
-    Builder::ConvSpec s0;
+    ConvSpec s0;
     s0.name = name + ".Conv_0";
     s0.tA = tA; s0.tB = tB; s0.CA = CA; s0.CB = CB; s0.Ha = Ha; s0.Wa = Wa; s0.Hv = H; s0.Wv = W;
     s0.gn = name + ".GroupNorm_0"; s0.conv = name + ".Conv_0";
     s0.Ho = H; s0.Wo = W; s0.Cout = cout; s0.dense_off = dense_off;
     const int h1 = b.add_conv(s0, err);
     if (*err) return -1;
-    Builder::ConvSpec s1;
+    ConvSpec s1;
     s1.name = name;
     s1.tA = h1; s1.CA = cout; s1.Ha = H; s1.Wa = W; s1.Hv = H; s1.Wv = W;
     s1.gn = name + ".GroupNorm_1"; s1.conv = name + ".Conv_1";
     s1.Ho = H; s1.Wo = W; s1.Cout = cout;
     s1.scale = (float)(1.0 / std::sqrt(2.0));
+    s1.dropout = true;
     if (CA + CB != cout) {
         s1.tScA = tA; s1.tScB = tB; s1.CscA = CA; s1.CscB = CB; s1.Hsa = Ha; s1.Wsa = Wa; s1.nin = name + ".NIN_0";
     } else {
@@ -487,7 +497,7 @@ int build_plan(rdmi_ctx* c) {
 
     // ---- NCSNpp.forward data flow
     int H = c->H, W = c->W;
-    Builder::ConvSpec in;
+    ConvSpec in;
     in.name = "input_conv"; in.tA = -2; in.CA = a.channels; in.Ha = H; in.Wa = W; in.Hv = H; in.Wv = W;
     in.conv = "input_conv"; in.Ho = H; in.Wo = W; in.Cout = a.nf;
     int h = b.add_conv(in, &err);
@@ -506,7 +516,7 @@ int build_plan(rdmi_ctx* c) {
         }
         hs.push_back({h, ch, H, W});
         if (i != a.n_levels - 1) {
-            Builder::ConvSpec s;
+            ConvSpec s;
             s.name = "downsample." + std::to_string(i);
             s.tA = h; s.CA = ch; s.Ha = H; s.Wa = W; s.Hv = H; s.Wv = W;
             s.conv = s.name + ".Conv_0"; s.stride = 2; s.pad_lo = 0;
@@ -535,7 +545,7 @@ int build_plan(rdmi_ctx* c) {
             if (bs.attn) { h = b.add_attn("up_attn." + std::to_string(u), h, ch, H, W, &err); if (err) return err; }
         }
         if (k != a.n_levels - 1) {
-            Builder::ConvSpec s;
+            ConvSpec s;
             s.name = "upsample." + std::to_string(k);
             s.tA = h; s.CA = ch; s.Ha = H; s.Wa = W; s.Hv = 2 * H; s.Wv = 2 * W;
             s.conv = s.name + ".Conv_0"; s.Ho = 2 * H; s.Wo = 2 * W; s.Cout = ch;
@@ -545,7 +555,7 @@ int build_plan(rdmi_ctx* c) {
         }
     }
     if (H != c->H || W != c->W) return fail("network output grid %dx%d != input %dx%d", H, W, c->H, c->W);
-    Builder::ConvSpec out;
+    ConvSpec out;
     out.name = "out_conv"; out.tA = h; out.CA = ch; out.Ha = H; out.Wa = W; out.Hv = H; out.Wv = W;
     out.gn = "out_norm"; out.conv = "out_conv"; out.Ho = H; out.Wo = W; out.Cout = a.channels; out.to_output = true;
     b.add_conv(out, &err);
@@ -1236,6 +1246,8 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
 
 }  // namespace
 
+#include "train_plan.h"
+
 // ============================================================================================
 // C ABI
 // ============================================================================================
@@ -1296,6 +1308,12 @@ int rdmi_create(const rdmi_arch* arch, int max_batch, int H, int W, rdmi_ctx** o
 
 int rdmi_destroy(rdmi_ctx* c) {
     if (!c) return 0;
+    if (TrainPlan* T = get_train(c)) {
+        for (void* p : {(void*)T->d_jobs, (void*)T->d_wb, (void*)T->d_int, (void*)T->gws, (void*)T->G, (void*)T->GA, (void*)T->GS, (void*)T->ACT, (void*)T->zero_bias,
+                        (void*)T->gdense, (void*)T->gta, (void*)T->gh1, (void*)T->four, (void*)T->sig_copy, (void*)T->lab_copy}) if (p) (void)hipFree(p);
+        train_registry().erase(c);
+        delete T;
+    }
     void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -1412,10 +1430,11 @@ int rdmi_perturb(const float* batch, const float* z, const float* t, float* out,
     return 0;
 }
 
-int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch, const float* t, float* per_sample, int B,
-                 int E, double sigma_min, double sigma_max, int likelihood_weighting, int reduce_mean, void* stream) {
+int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch, const float* t, float* per_sample,
+                 float* dscore, int B, int E, double sigma_min, double sigma_max, int likelihood_weighting, int reduce_mean,
+                 void* stream) {
     if (!score || !perturbed || !batch || !t || !per_sample) return fail("null argument");
-    hipLaunchKernelGGL(sm_loss_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, score, perturbed, batch, t, per_sample, B, E,
+    hipLaunchKernelGGL(sm_loss_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, score, perturbed, batch, t, per_sample, dscore, B, E,
                        (float)sigma_min, (float)(sigma_max / sigma_min), g_const(sigma_min, sigma_max), likelihood_weighting, reduce_mean,
                        20, 10, 1e-2f);
     HIP_OK(hipGetLastError());

@@ -1,0 +1,442 @@
+// Training step on the layer plan: train-mode forward (all activations kept, dropout) and the backward pass.
+// Included by rdmi.hip after the plan builder.  Kernels: bwd_kernels.h (+ the forward conv kernel for data gradients).
+#pragma once
+
+namespace {
+
+struct BwdConv {
+    int op = -1;                         // forward op index
+    bool has_dgrad = false, has_sc = false, has_gn = false;
+    ConvArgs dgrad{}; int dgrad_cfg = 0; // GA = dgrad(G)
+    ConvArgs scgrad{}; int sc_cfg = 0;   // GS = G . Wn^T
+    size_t tab_off = 0, wtab_off = 0, sctab_off = 0;
+    size_t invA_start = 0, invA_list = 0, invS_start = 0, invS_list = 0;   // inverse nearest maps (int arena offsets)
+    bool has_invA = false, has_invS = false;
+    size_t wT_off = 0, wscT_off = 0;     // transposed packs in the backward weight arena
+    int p_w = -1, p_b = -1, p_gamma = -1, p_beta = -1, p_wsc = -1, p_bsc = -1;   // parameter indices (flat-grad slices)
+};
+
+struct TrainPlan {
+    bool ready = false;
+    std::vector<BwdConv> convs;          // one per forward conv op (same order as c->ops; attention ops are looked up separately)
+    std::vector<PackJob> jobs; std::vector<int> job_param;
+    PackJob* d_jobs = nullptr;
+    float* d_wb = nullptr; size_t wb_floats = 0;       // transposed weight packs
+    int* d_int = nullptr;
+    float* gws = nullptr;                // gradients of the activation tensors (same offsets as ws)
+    float *G = nullptr, *GA = nullptr, *GS = nullptr, *ACT = nullptr, *zero_bias = nullptr;
+    float *gdense = nullptr, *gta = nullptr, *gh1 = nullptr, *four = nullptr, *sig_copy = nullptr, *lab_copy = nullptr;
+    std::vector<size_t> poff;            // flat-gradient offset of every parameter
+    size_t ptotal = 0;
+    float drop_p = 0.f; uint64_t seed = 0; int last_B = 0; int label_rows = 0;
+};
+
+void conv_tile_cfg(ConvArgs& a, int& cfg) {
+    if (a.Cout_pad < 32) { cfg = 3; a.S = 1; a.BN = 16; }
+    else if (a.HWo >= 40) { cfg = 0; a.S = 1; a.BN = 64; }
+    else if (a.HWo >= 9) { cfg = 1; a.S = std::max(1, 64 / a.HWo); a.BN = 32; }
+    else { cfg = 2; a.S = std::max(1, 16 / a.HWo); a.BN = 32; }
+    if (cfg == 0 && a.Cout_pad % 64 != 0) { cfg = 1; a.BN = 32; }
+    a.Mpad = pad16(a.S * a.HWo);
+}
+
+}  // namespace
+
+struct rdmi_train { TrainPlan t; };
+
+namespace {
+
+std::map<rdmi_ctx*, TrainPlan*>& train_registry() { static std::map<rdmi_ctx*, TrainPlan*> r; return r; }
+
+int launch_small_gemm(const SgemmArgs& g, hipStream_t s) {
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(g.M * g.N, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, g);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
+    const size_t NBmax = (size_t)c->max_batch;
+    // ---- every activation keeps its own storage (no liveness reuse) + a gradient twin
+    {
+        size_t top = 0;
+        for (auto& t : c->tensors) { t.off = top; top += (t.per_sample() + 63) & ~(size_t)63; }
+        c->ws_per_sample = top;
+        if (c->ws) (void)hipFree(c->ws);
+        HIP_OK(hipMalloc((void**)&c->ws, top * NBmax * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.gws, top * NBmax * sizeof(float)));
+        for (auto& op : c->ops) {
+            auto tptr = [&](int t) -> float* { return t >= 0 ? c->ws + c->tensors[(size_t)t].off * NBmax : nullptr; };
+            if (op.kind == OP_CONV) {
+                ConvArgs& ca = op.conv;
+                ca.srcA = tptr(op.tA); ca.srcB = tptr(op.tB); ca.scA = tptr(op.tScA); ca.scB = tptr(op.tScB);
+                ca.resid = tptr(op.tRes); ca.out = tptr(op.out_tensor);
+            } else { op.attn.x = tptr(op.tA); op.attn.out = tptr(op.out_tensor); }
+        }
+        c->debug_taps = true;            // the layer plan is now the only valid plan for this context (fused plan spills differently)
+    }
+    T.poff.resize(c->params.size());
+    T.ptotal = 0;
+    for (size_t i = 0; i < c->params.size(); ++i) { T.poff[i] = T.ptotal; T.ptotal += c->params[i].numel; }
+
+    std::vector<int> ints;
+    size_t wb = 0;
+    auto alloc_wb = [&](size_t n) { size_t o = wb; wb += (n + 63) & ~(size_t)63; return o; };
+    size_t maxG = 1, maxV = 1, maxS = 1;
+    auto gptr = [&](int t) -> float* { return t >= 0 ? T.gws + c->tensors[(size_t)t].off * NBmax : nullptr; };
+    (void)gptr;
+    T.convs.clear();
+    for (size_t oi = 0; oi < c->ops.size(); ++oi) {
+        const Op& op = c->ops[oi];
+        if (op.kind != OP_CONV) continue;
+        const ConvSpec& sp = op.spec;
+        const ConvArgs& fa = op.conv;
+        BwdConv b;
+        b.op = (int)oi;
+        const int Cin = sp.CA + sp.CB;
+        b.has_gn = !sp.gn.empty();
+        b.has_dgrad = !op.a_is_input;
+        b.has_sc = fa.Csc > 0;
+        b.p_w = c->pindex.at(sp.conv + ".weight"); b.p_b = c->pindex.at(sp.conv + ".bias");
+        if (b.has_gn) { b.p_gamma = c->pindex.at(sp.gn + ".weight"); b.p_beta = c->pindex.at(sp.gn + ".bias"); }
+        if (b.has_sc) { b.p_wsc = c->pindex.at(sp.nin + ".W"); b.p_bsc = c->pindex.at(sp.nin + ".b"); }
+        maxG = std::max(maxG, (size_t)fa.HWo * pad16(sp.Cout));
+        maxV = std::max(maxV, (size_t)fa.HWv * fa.Cv);
+        if (b.has_sc) maxS = std::max(maxS, (size_t)fa.HWo * fa.Csc);
+        // forward tap table per sample: [HWo][9] -> virtual input pixel or -1 (weight gradient)
+        b.wtab_off = ints.size();
+        for (int o = 0; o < fa.HWo; ++o) {
+            const int oy = o / sp.Wo, ox = o % sp.Wo;
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy * sp.stride + t / 3 - sp.pad_lo, ix = ox * sp.stride + t % 3 - sp.pad_lo;
+                ints.push_back((iy >= 0 && iy < sp.Hv && ix >= 0 && ix < sp.Wv) ? iy * sp.Wv + ix : -1);
+            }
+        }
+        if (b.has_dgrad) {
+            // data gradient = conv over G (grid Ho x Wo, Cout channels) producing the virtual-input grid (Hv x Wv, Cin channels)
+            ConvArgs& d = b.dgrad;
+            d = ConvArgs{};
+            d.CA = sp.Cout; d.CB = 0; d.Cv = pad16(sp.Cout);
+            d.HWa = fa.HWo; d.HWv = fa.HWo; d.HWo = fa.HWv; d.ntap = 9; d.G = 0;
+            d.Cout = Cin; d.Cout_pad = pad16(Cin); d.out_scale = 1.f; d.eps = 1e-6f;
+            conv_tile_cfg(d, b.dgrad_cfg);
+            if (conv_lds_bytes(d) > 160 * 1024) return fail("backward of %s: LDS tile too large", sp.name.c_str());
+            // adjoint table: row m = s*HWv + v (virtual input pixel), tap t -> LDS row s*HWo + o with in(o, t) == v
+            b.tab_off = ints.size();
+            const int zrow = d.S * d.HWv;                // (d.HWv is the dgrad conv's input = forward output grid)
+            for (int m = 0; m < d.Mpad; ++m) {
+                const int sidx = m / d.HWo, v = m % d.HWo;
+                const bool real = m < d.S * d.HWo;
+                const int vy = v / sp.Wv, vx = v % sp.Wv;
+                for (int t = 0; t < 9; ++t) {
+                    int row = zrow;
+                    const int ny = vy - (t / 3 - sp.pad_lo), nx = vx - (t % 3 - sp.pad_lo);
+                    if (real && ny >= 0 && nx >= 0 && ny % sp.stride == 0 && nx % sp.stride == 0) {
+                        const int oy = ny / sp.stride, ox = nx / sp.stride;
+                        if (oy < sp.Ho && ox < sp.Wo) row = sidx * d.HWv + oy * sp.Wo + ox;
+                    }
+                    ints.push_back(row);
+                }
+                ints.push_back(zrow);                    // shortcut column unused
+            }
+            // transposed weights: K = co, N = ci : packed[t][co/16][ci_pad][16] = W[co][ci][t]
+            b.wT_off = alloc_wb((size_t)9 * d.Cv * d.Cout_pad);
+            PackJob j{};
+            j.dst = reinterpret_cast<float*>(b.wT_off);
+            j.Cin = sp.Cout; j.Cout = Cin; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 9;
+            j.s_co = 9; j.s_ci = (long)Cin * 9; j.s_t = 1; j.kind = 0;     // "co" of the job = ci of W, "ci" of the job = co of W
+            T.jobs.push_back(j); T.job_param.push_back(b.p_w);
+        }
+        if (b.has_sc) {
+            ConvArgs& d = b.scgrad;
+            d = ConvArgs{};
+            const int Csc = sp.CscA + sp.CscB;
+            d.CA = sp.Cout; d.CB = 0; d.Cv = pad16(sp.Cout);
+            d.HWa = fa.HWo; d.HWv = fa.HWo; d.HWo = fa.HWo; d.ntap = 1; d.G = 0;
+            d.Cout = Csc; d.Cout_pad = pad16(Csc); d.out_scale = 1.f; d.eps = 1e-6f;
+            conv_tile_cfg(d, b.sc_cfg);
+            b.sctab_off = ints.size();
+            for (int m = 0; m < d.Mpad; ++m) { ints.push_back(m < d.S * d.HWo ? m : d.S * d.HWv); ints.push_back(d.S * d.HWv); }
+            b.wscT_off = alloc_wb((size_t)d.Cv * d.Cout_pad);
+            PackJob j{};
+            j.dst = reinterpret_cast<float*>(b.wscT_off);
+            j.Cin = sp.Cout; j.Cout = Csc; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 1;
+            j.s_co = sp.Cout; j.s_ci = 1; j.s_t = 0; j.kind = 0;            // NIN W [in=Csc][out=Cout]: job "co" = in, job "ci" = out
+            T.jobs.push_back(j); T.job_param.push_back(b.p_wsc);
+        }
+        // inverse nearest maps for the scatter of gradients back to mapped sources
+        auto inverse = [&](const std::vector<int>& map, int HWsrc, size_t& st, size_t& li) {
+            std::vector<std::vector<int>> inv((size_t)HWsrc);
+            for (size_t v = 0; v < map.size(); ++v) inv[(size_t)map[v]].push_back((int)v);
+            st = ints.size();
+            int acc = 0;
+            for (int s2 = 0; s2 < HWsrc; ++s2) { ints.push_back(acc); acc += (int)inv[(size_t)s2].size(); }
+            ints.push_back(acc);
+            li = ints.size();
+            for (auto& l : inv) for (int v : l) ints.push_back(v);
+        };
+        if (op.has_mapA) { inverse(op.mapA, fa.HWa, b.invA_start, b.invA_list); b.has_invA = true; }
+        if (op.has_mapSc) { inverse(op.mapSc, fa.HWsa, b.invS_start, b.invS_list); b.has_invS = true; }
+        T.convs.push_back(b);
+    }
+    T.wb_floats = std::max<size_t>(wb, 64);
+    HIP_OK(hipMalloc((void**)&T.d_wb, T.wb_floats * sizeof(float)));
+    HIP_OK(hipMemset(T.d_wb, 0, T.wb_floats * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.d_int, std::max<size_t>(ints.size(), 1) * sizeof(int)));
+    HIP_OK(hipMemcpy(T.d_int, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc((void**)&T.d_jobs, std::max<size_t>(T.jobs.size(), 1) * sizeof(PackJob)));
+    for (auto& j : T.jobs) j.dst = T.d_wb + reinterpret_cast<size_t>(j.dst);
+    HIP_OK(hipMalloc((void**)&T.G, maxG * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.GA, maxV * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.ACT, maxV * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.GS, maxS * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.zero_bias, 1024 * sizeof(float)));
+    HIP_OK(hipMemset(T.zero_bias, 0, 1024 * sizeof(float)));
+    const size_t Mp = (size_t)pad16(c->max_batch);
+    HIP_OK(hipMalloc((void**)&T.gdense, Mp * c->dense_total * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.gta, Mp * c->temb * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.gh1, Mp * c->temb * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.four, Mp * 2 * c->arch.nf * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.sig_copy, Mp * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.lab_copy, Mp * std::max(1, c->arch.num_classes) * sizeof(float)));
+    // resolve pointers of the data-gradient convs
+    for (auto& b : T.convs) {
+        if (b.has_dgrad) {
+            ConvArgs& d = b.dgrad;
+            d.srcA = T.G; d.tab = T.d_int + b.tab_off; d.wpk = T.d_wb + b.wT_off; d.bias = T.zero_bias; d.out = T.GA;
+        }
+        if (b.has_sc) {
+            ConvArgs& d = b.scgrad;
+            d.srcA = T.G; d.tab = T.d_int + b.sctab_off; d.wpk = T.d_wb + b.wscT_off; d.bias = T.zero_bias; d.out = T.GS;
+        }
+    }
+    T.ready = true;
+    return 0;
+}
+
+TrainPlan* get_train(rdmi_ctx* c) {
+    auto& r = train_registry();
+    auto it = r.find(c);
+    return it == r.end() ? nullptr : it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdmi_enable_training(rdmi_ctx* c) {
+    if (!c) return fail("null context");
+    if (get_train(c)) return 0;
+    TrainPlan* T = new TrainPlan();
+    int e = 0;
+    try { e = build_train_plan(c, *T); } catch (const std::exception& ex) { e = fail("training plan: %s", ex.what()); }
+    if (e) { delete T; return e; }
+    train_registry()[c] = T;
+    return 0;
+}
+
+// Train-mode forward: layer plan, every activation kept, Dropout_0 (p) on the input of every Conv_1.
+int rdmi_train_forward(rdmi_ctx* c, const float* x, const float* sigma, const float* labels, float* out, int B, float dropout_p,
+                       uint64_t seed, void* stream) {
+    if (!c || !x || !sigma || !out) return fail("null argument");
+    TrainPlan* T = get_train(c);
+    if (!T) return fail("call rdmi_enable_training first");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = do_repack(c, s)) return e;
+    T->drop_p = dropout_p; T->seed = seed; T->last_B = B;
+    for (size_t oi = 0; oi < c->ops.size(); ++oi) {
+        Op& op = c->ops[oi];
+        if (op.kind == OP_CONV) { op.conv.drop_p = op.dropout ? dropout_p : 0.f; op.conv.drop_seed = seed; op.conv.op_id = (uint32_t)oi; }
+    }
+    HIP_OK(hipMemcpyAsync(T->sig_copy, sigma, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (labels) HIP_OK(hipMemcpyAsync(T->lab_copy, labels, (size_t)B * c->arch.num_classes * sizeof(float), hipMemcpyDeviceToDevice, s));
+    FwdIn f{x, 0, sigma, 0, 0.f, 0, 0.f, 0.f, labels, B, out, B};
+    const bool keep = c->use_fused;
+    c->use_fused = false;
+    int e = run_forward(c, f, s);
+    c->use_fused = keep;
+    for (auto& op : c->ops) if (op.kind == OP_CONV) op.conv.drop_p = 0.f;
+    return e;
+}
+
+// Backward of the last rdmi_train_forward: grad_out [B,1,H,W] -> every parameter gradient, written (not accumulated) into
+// grads_flat in the reference's parameter order (offsets = running sum of numel; time_embed.W stays zero).
+int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t grads_numel, const float* x, void* stream) {
+    if (!c || !grad_out || !grads_flat || !x) return fail("null argument");
+    TrainPlan* Tp = get_train(c);
+    if (!Tp) return fail("call rdmi_enable_training first");
+    TrainPlan& T = *Tp;
+    if (grads_numel != T.ptotal) return fail("grads buffer holds %zu floats, the model has %zu parameters", grads_numel, T.ptotal);
+    hipStream_t s = (hipStream_t)stream;
+    const int NB = T.last_B;
+    const size_t NBmax = (size_t)c->max_batch;
+    // transposed packs
+    for (size_t i = 0; i < T.jobs.size(); ++i) T.jobs[i].src = c->params[(size_t)T.job_param[i]].ptr;
+    if (!T.jobs.empty()) {
+        HIP_OK(hipMemcpyAsync(T.d_jobs, T.jobs.data(), T.jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(pack_kernel, dim3(32, (unsigned)T.jobs.size()), dim3(RDMI_THREADS), 0, s, (const PackJob*)T.d_jobs);
+    }
+    HIP_OK(hipMemsetAsync(grads_flat, 0, T.ptotal * sizeof(float), s));
+    HIP_OK(hipMemsetAsync(T.gws, 0, c->ws_per_sample * NBmax * sizeof(float), s));
+    HIP_OK(hipMemsetAsync(T.gdense, 0, (size_t)pad16(c->max_batch) * c->dense_total * sizeof(float), s));
+    auto gptr = [&](int t) -> float* { return t >= 0 ? T.gws + c->tensors[(size_t)t].off * NBmax : nullptr; };
+    auto pgrad = [&](int pi) -> float* { return pi >= 0 ? grads_flat + T.poff[(size_t)pi] : nullptr; };
+    static bool attr = false;
+    if (!attr) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    // map forward op index -> backward conv record
+    std::map<int, const BwdConv*> bmap;
+    for (auto& b : T.convs) bmap[b.op] = &b;
+
+    for (int oi = (int)c->ops.size() - 1; oi >= 0; --oi) {
+        const Op& op = c->ops[(size_t)oi];
+        if (op.kind == OP_ATTN) {
+            AttnBwdArgs a{};
+            a.x = op.attn.x; a.gOut = gptr(op.out_tensor); a.gX = gptr(op.tA);
+            a.gamma = op.attn.gamma; a.beta = op.attn.beta;
+            a.dgamma = pgrad(c->pindex.at(op.name + ".GroupNorm_0.weight")); a.dbeta = pgrad(c->pindex.at(op.name + ".GroupNorm_0.bias"));
+            for (int k = 0; k < 4; ++k) {
+                const int pw = c->pindex.at(op.name + ".NIN_" + std::to_string(k) + ".W"), pb = c->pindex.at(op.name + ".NIN_" + std::to_string(k) + ".b");
+                a.W[k] = c->params[(size_t)pw].ptr; a.b[k] = c->params[(size_t)pb].ptr; a.dW[k] = pgrad(pw); a.db[k] = pgrad(pb);
+            }
+            a.NB = NB; a.L = op.attn.L; a.G = op.attn.G; a.eps = op.attn.eps; a.scale = op.attn.scale; a.out_scale = op.attn.out_scale;
+            hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3((unsigned)NB), dim3(RDMI_THREADS), attn_bwd_lds_bytes<64>(a.L, a.G), s, a);
+            HIP_OK(hipGetLastError());
+            continue;
+        }
+        const BwdConv& b = *bmap.at(oi);
+        const ConvSpec& sp = op.spec;
+        const ConvArgs& fa = op.conv;
+        const int Cin = sp.CA + sp.CB;
+        const float* gY = op.out_is_output ? grad_out : gptr(op.out_tensor);
+        const long nG = (long)NB * fa.HWo * sp.Cout;
+        // G = scale * gY (+ identity residual)
+        hipLaunchKernelGGL(bwd_scale_kernel, dim3((unsigned)ceil_div((int)nG, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, gY, T.G, gptr(op.tRes),
+                           fa.out_scale, nG);
+        // bias / NIN-bias / Dense_0 gradients
+        hipLaunchKernelGGL(bwd_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, (const float*)T.G, op.use_dense ? T.gdense : (float*)nullptr,
+                           c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout);
+        // data gradient w.r.t. the activated input
+        if (b.has_dgrad) {
+            ConvArgs d = b.dgrad; d.NB = NB;
+            if (int e = launch_conv(b.dgrad_cfg, d, s)) return e;
+        }
+        // GroupNorm / SiLU / dropout backward (+ materialise ACT for the weight gradient)
+        {
+            GnBwdArgs g{};
+            g.srcA = op.a_is_input ? x : fa.srcA; g.srcB = fa.srcB; g.mapA = fa.mapA;
+            g.CA = fa.CA; g.CB = fa.CB; g.Cv = fa.Cv; g.HWa = fa.HWa; g.HWv = fa.HWv; g.srcA_mod = 0; g.NB = NB;
+            g.GA = T.GA; g.ACT = T.ACT;
+            g.has_gn = b.has_gn ? 1 : 0; g.G = fa.G; g.eps = fa.eps;
+            if (b.has_gn) { g.gamma = fa.gamma; g.beta = fa.beta; g.dgamma = pgrad(b.p_gamma); g.dbeta = pgrad(b.p_beta); }
+            g.drop_p = op.dropout ? T.drop_p : 0.f; g.seed = T.seed; g.op_id = (uint32_t)oi;
+            const size_t lds = ((size_t)2 * (fa.HWv + 1) * (fa.Cv + 4) + 4 * 32) * 4;
+            if (lds > 160 * 1024) return fail("gn backward of %s: LDS %zu B", sp.name.c_str(), lds);
+            hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), lds, s, g);
+        }
+        // weight gradient (reference OIHW layout): dW[co][ci][t] += sum ACT[in(o,t)][ci] G[o][co]
+        {
+            WgradArgs w{};
+            w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_w); w.tab = T.d_int + b.wtab_off;
+            w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
+            w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
+            w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
+            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(9, (unsigned)ceil_div(Cin, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS), 0, s, w);
+        }
+        // scatter the input gradient to the source tensors
+        if (b.has_dgrad) {
+            const long tot = (long)NB * fa.HWa * fa.CA + (long)NB * fa.HWv * fa.CB;
+            hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GA,
+                               gptr(op.tA), gptr(op.tB), b.has_invA ? T.d_int + b.invA_start : (const int*)nullptr,
+                               b.has_invA ? T.d_int + b.invA_list : (const int*)nullptr, NB, fa.HWa, fa.HWv, fa.CA, fa.CB, fa.Cv);
+        }
+        // NIN shortcut: data gradient, weight gradient, scatter
+        if (b.has_sc) {
+            ConvArgs d = b.scgrad; d.NB = NB;
+            if (int e = launch_conv(b.sc_cfg, d, s)) return e;
+            GnBwdArgs g{};
+            g.srcA = fa.scA; g.srcB = fa.scB; g.mapA = fa.mapSc;
+            g.CA = fa.CscA; g.CB = fa.CscB; g.Cv = fa.Csc; g.HWa = fa.HWsa; g.HWv = fa.HWo; g.NB = NB;
+            g.GA = T.GS; g.ACT = T.ACT; g.has_gn = 0;
+            const size_t lds = ((size_t)2 * (fa.HWo + 1) * (fa.Csc + 4) + 4 * 32) * 4;
+            hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), lds, s, g);
+            WgradArgs w{};
+            const int Csc = sp.CscA + sp.CscB;
+            w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
+            w.NB = NB; w.HWv = fa.HWo; w.HWo = fa.HWo; w.Cin = Csc; w.Cout = sp.Cout; w.ntap = 1; w.lda = fa.Csc;
+            w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
+            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(1, (unsigned)ceil_div(Csc, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS), 0, s, w);
+            const long tot = (long)NB * fa.HWsa * fa.CscA + (long)NB * fa.HWo * fa.CscB;
+            hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GS,
+                               gptr(op.tScA), gptr(op.tScB), b.has_invS ? T.d_int + b.invS_start : (const int*)nullptr,
+                               b.has_invS ? T.d_int + b.invS_list : (const int*)nullptr, NB, fa.HWsa, fa.HWo, fa.CscA, fa.CscB, fa.Csc);
+        }
+        HIP_OK(hipGetLastError());
+    }
+
+    // ---- embedding backward: Dense_0 (x17) -> SiLU -> [label_emb, time_mlp.2] -> SiLU -> time_mlp.0
+    const int Tm = c->temb, DT = c->dense_total, nf = c->arch.nf;
+    {
+        Layout L = build_layout(c);
+        std::vector<std::pair<std::string, int>> blocks;
+        for (auto& d : L.down) blocks.push_back({d.name, d.cout});
+        blocks.push_back({"mid_block1", L.mid_ch}); blocks.push_back({"mid_block2", L.mid_ch});
+        for (auto& u : L.up) blocks.push_back({u.name, u.cout});
+        int off = 0;
+        bool first = true;
+        for (auto& bl : blocks) {
+            const int pw = c->pindex.at(bl.first + ".Dense_0.weight"), pb = c->pindex.at(bl.first + ".Dense_0.bias");
+            SgemmArgs g{};   // dWd[co][k] = sum_n gdense[n][off+co] * silu(temb[n][k])
+            g.A = T.gdense + off; g.a_m = 1; g.a_k = DT; g.a_act = 0;
+            g.B = c->d_temb; g.b_k = Tm; g.b_n = 1; g.b_act = 1;
+            g.C = pgrad(pw); g.c_m = Tm; g.c_n = 1; g.accumulate = 0; g.M = bl.second; g.N = Tm; g.K = NB;
+            if (int e = launch_small_gemm(g, s)) return e;
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(bl.second, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)(T.gdense + off), pgrad(pb), NB, bl.second, DT);
+            SgemmArgs h{};   // gta[n][k] (+)= sum_co gdense[n][off+co] * Wd[co][k]
+            h.A = T.gdense + off; h.a_m = DT; h.a_k = 1; h.B = c->params[(size_t)pw].ptr; h.b_k = Tm; h.b_n = 1;
+            h.C = T.gta; h.c_m = Tm; h.c_n = 1; h.accumulate = first ? 0 : 1; h.M = NB; h.N = Tm; h.K = bl.second;
+            if (int e = launch_small_gemm(h, s)) return e;
+            first = false;
+            off += bl.second;
+        }
+        hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)ceil_div(NB * Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, T.gta, (const float*)c->d_temb, (long)NB * Tm);
+        // gta is now g(temb)
+        if (c->arch.conditional) {
+            const int pw = c->pindex.at("label_emb.weight"), pb = c->pindex.at("label_emb.bias"), nc = c->arch.num_classes;
+            SgemmArgs g{};   // dWl[k][cl] = sum_n gtemb[n][k] * labels[n][cl]
+            g.A = T.gta; g.a_m = 1; g.a_k = Tm; g.B = T.lab_copy; g.b_k = nc; g.b_n = 1; g.C = pgrad(pw); g.c_m = nc; g.c_n = 1;
+            g.M = Tm; g.N = nc; g.K = NB;
+            if (int e = launch_small_gemm(g, s)) return e;
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
+        }
+        {
+            const int pw = c->pindex.at("time_mlp.2.weight"), pb = c->pindex.at("time_mlp.2.bias");
+            SgemmArgs g{};   // dW2[k][j] = sum_n gtemb[n][k] * silu(h1[n][j])
+            g.A = T.gta; g.a_m = 1; g.a_k = Tm; g.B = c->d_h1; g.b_k = Tm; g.b_n = 1; g.b_act = 1; g.C = pgrad(pw); g.c_m = Tm; g.c_n = 1;
+            g.M = Tm; g.N = Tm; g.K = NB;
+            if (int e = launch_small_gemm(g, s)) return e;
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
+            SgemmArgs h{};   // gh1[n][j] = sum_k gtemb[n][k] * W2[k][j]
+            h.A = T.gta; h.a_m = Tm; h.a_k = 1; h.B = c->params[(size_t)pw].ptr; h.b_k = Tm; h.b_n = 1; h.C = T.gh1; h.c_m = Tm; h.c_n = 1;
+            h.M = NB; h.N = Tm; h.K = Tm;
+            if (int e = launch_small_gemm(h, s)) return e;
+            hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)ceil_div(NB * Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, T.gh1, (const float*)c->d_h1, (long)NB * Tm);
+        }
+        {
+            const int pw = c->pindex.at("time_mlp.0.weight"), pb = c->pindex.at("time_mlp.0.bias");
+            hipLaunchKernelGGL(fourier_kernel, dim3((unsigned)ceil_div(NB * 2 * nf, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.sig_copy,
+                               c->params[(size_t)c->pindex.at("time_embed.W")].ptr, T.four, NB, nf);
+            SgemmArgs g{};   // dW0[j][f] = sum_n gh1[n][j] * four[n][f]
+            g.A = T.gh1; g.a_m = 1; g.a_k = Tm; g.B = T.four; g.b_k = 2 * nf; g.b_n = 1; g.C = pgrad(pw); g.c_m = 2 * nf; g.c_n = 1;
+            g.M = Tm; g.N = 2 * nf; g.K = NB;
+            if (int e = launch_small_gemm(g, s)) return e;
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.gh1, pgrad(pb), NB, Tm, Tm);
+        }
+        HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // extern "C"

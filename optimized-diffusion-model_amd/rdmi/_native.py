@@ -46,7 +46,10 @@ _PROTOS = {
     'rdmi_reflect': ([_F, _F, C.c_size_t, C.c_void_p], C.c_int),
     'rdmi_score_hk': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_perturb': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
-    'rdmi_sm_loss': ([_F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    'rdmi_sm_loss': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    'rdmi_enable_training': ([C.c_void_p], C.c_int),
+    'rdmi_train_forward': ([C.c_void_p, _F, _F, _F, _F, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
+    'rdmi_backward': ([C.c_void_p, _F, _F, C.c_size_t, _F, C.c_void_p], C.c_int),
     'rdmi_em_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
     'rdmi_langevin_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_pc_sample': ([C.c_void_p, _F, _F, _F, _F, _F, _F, C.c_int, C.POINTER(PcOpts), C.c_uint, C.c_void_p], C.c_int),
@@ -173,6 +176,19 @@ class Context:
             check(lib().rdmi_cf_score(self._h, ptr(x), ptr(t), ptr(labels), ptr(weight), ptr(out), x.shape[0], smin, smax,
                                       flags, stream_of(x)))
 
+    def enable_training(self):
+        with self._guard():
+            check(lib().rdmi_enable_training(self._h))
+
+    def train_forward(self, x, sigma, labels, out, dropout_p, seed):
+        with self._guard():
+            check(lib().rdmi_train_forward(self._h, ptr(x), ptr(sigma), ptr(labels), ptr(out), x.shape[0], float(dropout_p),
+                                           int(seed), stream_of(x)))
+
+    def backward(self, grad_out, grads_flat, x):
+        with self._guard():
+            check(lib().rdmi_backward(self._h, ptr(grad_out), ptr(grads_flat), grads_flat.numel(), ptr(x), stream_of(x)))
+
     def pc_sample(self, x, labels, weight, noise, trace, teacher, opts, flags=0):
         with self._guard():
             check(lib().rdmi_pc_sample(self._h, ptr(x), ptr(labels), ptr(weight), ptr(noise), ptr(trace), ptr(teacher),
@@ -247,14 +263,15 @@ def perturb(batch, z, t, smin, smax):
     return out
 
 
-def sm_loss(score, perturbed, batch, t, smin, smax, likelihood_weighting, reduce_mean):
+def sm_loss(score, perturbed, batch, t, smin, smax, likelihood_weighting, reduce_mean, want_grad=False):
     require_device(batch)
     B = batch.shape[0]
     per = torch.empty(B, dtype=torch.float32, device=batch.device)
+    dscore = torch.empty_like(batch, dtype=torch.float32) if want_grad else None
     check(lib().rdmi_sm_loss(ptr(score.contiguous()), ptr(perturbed.contiguous()), ptr(batch.contiguous()),
-                             ptr(t.contiguous().float()), ptr(per), B, batch.numel() // B, smin, smax,
+                             ptr(t.contiguous().float()), ptr(per), ptr(dscore), B, batch.numel() // B, smin, smax,
                              int(bool(likelihood_weighting)), int(bool(reduce_mean)), stream_of(batch)))
-    return per
+    return (per, dscore) if want_grad else per
 
 
 def em_update(x, score, z, t, N, smin, smax):

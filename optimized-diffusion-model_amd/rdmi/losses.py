@@ -7,9 +7,10 @@ get_sde_loss_fn, get_step_fn with the reference's signatures and `state` dict co
 What runs where (round 1):
   * the loss arithmetic -- perturbation + reflection, the reflected-heat-kernel target (cube.score_hk) and the
     weighted squared error reduction -- is two HIP kernels (rdmi_perturb, rdmi_sm_loss);
-  * the network forward is the fused HIP U-Net; this covers the EVALUATION step end to end (EMA swap, no_grad);
-  * the TRAINING step needs the network backward, which is not built yet: step_fn(train=True) raises
-    NotImplementedError instead of silently falling back to a torch graph ("Not built yet").
+  * evaluation step: the fused HIP U-Net forward under no_grad with the EMA weights swapped in;
+  * training step: train-mode forward (Dropout_0 by in-kernel Philox, label drop) and the NCSN++ backward are HIP
+    kernels on the layer plan (csrc/train_plan.h, bwd_kernels.h) behind a torch.autograd.Function; Adam, gradient
+    clipping and the EMA update are the reference's own torch calls on the parameter tensors.
 The reference's per-call NaN hooks (RD/losses.py:95-104) are deliberately not reproduced: they leak one hook per
 parameter per call and slow training from 0.5 s to 38 s per step.
 """
@@ -56,18 +57,17 @@ def get_sde_loss_fn(sde, train, reduce_mean=True, likelihood_weighting=True, eps
     """RD/losses.py:52-107.  loss_fn(model, batch, class_labels=None) -> scalar tensor."""
 
     def loss_fn(model, batch, class_labels=None):
-        if train:
-            raise NotImplementedError(
-                'training loss: the NCSN++ backward pass is not built in librdmi yet (round 1 covers sampling and the '
-                'evaluation loss); refusing to fall back to a torch autograd graph')
-        score_fn = mutils.get_score_fn(sde, model, train=False)
+        score_fn = mutils.get_score_fn(sde, model, train=train)
         t = torch.rand(batch.shape[0], device=batch.device) * (sde.T - eps) + eps
         z = torch.randn_like(batch)
         smin, smax = float(sde.sigma_min), float(sde.sigma_max)
         perturbed = _native.perturb(batch.float(), z, t, smin, smax)                  # reflect(mean + std z)
-        with torch.no_grad():
-            score = score_fn(perturbed, t, class_labels=class_labels)
-        per = _native.sm_loss(score, perturbed, batch.float(), t, smin, smax, likelihood_weighting, reduce_mean)
+        score = score_fn(perturbed, t, class_labels=class_labels)
+        if score.requires_grad:
+            from . import autograd_fn
+            per = autograd_fn.sm_loss(score, perturbed, batch.float(), t, smin, smax, likelihood_weighting, reduce_mean)
+        else:
+            per = _native.sm_loss(score, perturbed, batch.float(), t, smin, smax, likelihood_weighting, reduce_mean)
         return torch.mean(per)
 
     return loss_fn
@@ -82,7 +82,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, likelihood_weig
         if train:
             optimizer = state['optimizer']
             optimizer.zero_grad()
-            loss = loss_fn(model, batch, class_labels=class_labels)       # raises: backward not built (see module doc)
+            loss = loss_fn(model, batch, class_labels=class_labels)
             loss.backward()
             optimize_fn(optimizer, model.parameters(), step=state['step'], scaler=state['scaler'])
             state['step'] += 1

@@ -189,6 +189,20 @@ class NCSNpp(nn.Module):
         ctx.bind((n, t) for n, t in self.state_dict(keep_vars=True).items())
         return ctx
 
+    def train_context(self, model_batch, H, W, device):
+        """A dedicated rdmi_ctx for training (layer plan, per-tensor activation storage, gradient workspace)."""
+        device = torch.device(device)
+        key = ('train', str(device), H, W)
+        ctx = self._ctx.get(key)
+        if ctx is None or ctx.max_batch < model_batch:
+            if ctx is not None:
+                ctx.close()
+            ctx = _native.Context(self._arch(), max(model_batch, 16), H, W, device)
+            ctx.enable_training()
+            self._ctx[key] = ctx
+        ctx.bind((n, t) for n, t in self.state_dict(keep_vars=True).items())
+        return ctx
+
     def _prep(self, x):
         _native.require_device(x)
         p = next(self.parameters())

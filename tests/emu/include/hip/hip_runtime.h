@@ -83,6 +83,14 @@ inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_em
 }
 
 inline long long clock64() { return 0; }
+inline float atomicAdd(float* p, float v) {   // workgroups run on parallel OS threads: a real atomic
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    unsigned old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
+    float f;
+    do { std::memcpy(&f, &old, 4); f += v; std::memcpy(&nw, &f, 4); } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    std::memcpy(&f, &old, 4);
+    return f;
+}
 inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
 template <class T, class U> inline T __builtin_bit_cast_emu(U u) { T t; std::memcpy(&t, &u, sizeof(T)); return t; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values
