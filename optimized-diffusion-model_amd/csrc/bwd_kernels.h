@@ -170,40 +170,53 @@ __global__ __launch_bounds__(RDMI_THREADS) void scatter_grad_kernel(const float*
 
 // Weight gradient: dW[co][ci][tap] (reference OIHW layout, or NIN [ci][co] / Linear [co][ci] through the strides)
 //   += sum_{n, o} ACT[n][in(o, tap)][ci] * G[n][o][co]
-// grid = (ntap, ceil(Cin/32), ceil(Cout/32)); a workgroup owns a 32x32 (ci x co) tile of one tap: wave w owns the 16x16
-// sub-tile (w&1, w>>1) and contracts over every (sample, output pixel) with MFMA 16x16x4 (k = 4 pixels per instruction).
+// grid = (ntap * ksplit, ceil(Cin/32), ceil(Cout/32)): a workgroup owns a 32x32 (ci x co) tile of one tap for a slice of
+// the samples (split-K over the batch, partial tiles merged with fp32 atomics); wave w owns the 16x16 sub-tile
+// (w&1, w>>1) and contracts over (sample, output pixel) with MFMA 16x16x4, eight k-steps of loads in flight per iteration.
 struct WgradArgs {
     const float* ACT; const float* G; float* dW;
     const int* tab;        // [HWo][ntap] input pixel of (output pixel, tap) or -1   (null: identity, 1 tap)
     int NB, HWv, HWo, Cin, Cout, ntap;
     int lda;               // channels per pixel of ACT (>= Cin: padded input channels)
+    int ksplit;            // number of sample slices
     long s_co, s_ci, s_t;  // strides of dW
 };
 
 __global__ __launch_bounds__(RDMI_THREADS) void wgrad_mfma_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lrow = lane & 15, kq = lane >> 4;
-    const int tap = blockIdx.x;
+    const int tap = blockIdx.x % a.ntap, slice = blockIdx.x / a.ntap;
+    int* vt = reinterpret_cast<int*>(rdmi_lds);                  // [HWo4] input pixel of each output pixel for this tap (-1: none)
+    const int HWo4 = (a.HWo + 3) & ~3;
+    for (int o = threadIdx.x; o < HWo4; o += RDMI_THREADS) vt[o] = o < a.HWo ? (a.tab ? a.tab[o * a.ntap + tap] : o) : -1;
+    __syncthreads();
     const int ci = blockIdx.y * 32 + (wave & 1) * 16 + lrow;      // A row  (this lane's input channel)
     const int co = blockIdx.z * 32 + (wave >> 1) * 16 + lrow;     // B col  (this lane's output channel)
+    const bool ci_ok = ci < a.Cin, co_ok = co < a.Cout;
+    const int per = (a.NB + a.ksplit - 1) / a.ksplit;
+    const int n_lo = slice * per, n_hi = min(a.NB, n_lo + per);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int K = a.NB * a.HWo;
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + kq;                                    // this lane's (sample, output pixel)
-        float av = 0.f, bv = 0.f;
-        if (k < K) {
-            const int n = k / a.HWo, o = k - n * a.HWo;
-            const int v = a.tab ? a.tab[o * a.ntap + tap] : o;
-            if (v >= 0 && ci < a.Cin) av = a.ACT[((size_t)n * a.HWv + v) * a.lda + ci];
-            if (co < a.Cout) bv = a.G[((size_t)n * a.HWo + o) * a.Cout + co];
+    constexpr int U = 8;                                          // k-steps (of 4 pixels) per unrolled iteration
+    for (int n = n_lo; n < n_hi; ++n) {
+        const float* An = a.ACT + (size_t)n * a.HWv * a.lda + ci;
+        const float* Gn = a.G + (size_t)n * a.HWo * a.Cout + co;
+        for (int o0 = 0; o0 < HWo4; o0 += 4 * U) {
+            float av[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int o = o0 + 4 * u + kq;
+                const int v = o < HWo4 ? vt[o] : -1;
+                av[u] = (v >= 0 && ci_ok) ? ldg1(An + (size_t)v * a.lda) : 0.f;
+                bv[u] = (o < a.HWo && co_ok) ? ldg1(Gn + (size_t)o * a.Cout) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = mfma16(av[u], bv[u], acc);
         }
-        acc = mfma16(av, bv, acc);
     }
     // D[row = ci_local][col = co_local]: lane holds col = lrow, rows kq*4 + r
-    const int co_out = blockIdx.z * 32 + (wave >> 1) * 16 + lrow;
     for (int r = 0; r < 4; ++r) {
         const int ci_out = blockIdx.y * 32 + (wave & 1) * 16 + kq * 4 + r;
-        if (ci_out < a.Cin && co_out < a.Cout) atomicAdd(a.dW + co_out * a.s_co + ci_out * a.s_ci + tap * a.s_t, acc[r]);
+        if (ci_out < a.Cin && co_ok) atomicAdd(a.dW + co * a.s_co + ci_out * a.s_ci + tap * a.s_t, acc[r]);
     }
 }
 

@@ -343,7 +343,12 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
             w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
             w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
-            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(9, (unsigned)ceil_div(Cin, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS), 0, s, w);
+            {   // split the batch so that ~1000 workgroups exist whatever the layer's channel counts
+                const int tiles = 9 * ceil_div(Cin, 32) * ceil_div(sp.Cout, 32);
+                w.ksplit = std::max(1, std::min(NB, 1024 / tiles));
+                hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)(9 * w.ksplit), (unsigned)ceil_div(Cin, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS),
+                                   (size_t)(fa.HWo + 4) * 4, s, w);
+            }
         }
         // scatter the input gradient to the source tensors
         if (b.has_dgrad) {
@@ -367,7 +372,12 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
             w.NB = NB; w.HWv = fa.HWo; w.HWo = fa.HWo; w.Cin = Csc; w.Cout = sp.Cout; w.ntap = 1; w.lda = fa.Csc;
             w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
-            hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(1, (unsigned)ceil_div(Csc, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS), 0, s, w);
+            {
+                const int tiles = ceil_div(Csc, 32) * ceil_div(sp.Cout, 32);
+                w.ksplit = std::max(1, std::min(NB, 1024 / tiles));
+                hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)w.ksplit, (unsigned)ceil_div(Csc, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS),
+                                   (size_t)(fa.HWo + 4) * 4, s, w);
+            }
             const long tot = (long)NB * fa.HWsa * fa.CscA + (long)NB * fa.HWo * fa.CscB;
             hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GS,
                                gptr(op.tScA), gptr(op.tScB), b.has_invS ? T.d_int + b.invS_start : (const int*)nullptr,

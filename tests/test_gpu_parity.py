@@ -327,8 +327,11 @@ def test_dropout_and_label_drop_train_mode(env):
         return float(loss.detach()), model.out_conv.weight.grad.detach().clone(), model.time_mlp[2].weight.grad.detach().clone()
     l1, a1, b1 = run(11); l2, a2, b2 = run(11); l3, a3, b3 = run(12)
     assert np.isfinite(l1) and torch.isfinite(a1).all() and torch.isfinite(b1).all()
-    assert l1 == l2 and torch.equal(a1, a2) and torch.equal(b1, b2)
-    assert l1 != l3 and not torch.equal(a1, a3)
+    # same seed -> same masks: identical loss; gradients equal up to the fp32 atomic summation order of the split-K
+    # weight-gradient partials (documented non-determinism of float atomics)
+    assert l1 == l2
+    assert torch.allclose(a1, a2, rtol=1e-4, atol=1e-6 * float(a1.abs().max())) and torch.allclose(b1, b2, rtol=1e-4, atol=1e-6 * float(b1.abs().max()))
+    assert l1 != l3 and not torch.allclose(a1, a3, rtol=1e-3, atol=1e-4 * float(a1.abs().max()))
     # directional derivative: loss(w + h d) - loss(w - h d) ~ 2 h <grad, d> along d = grad / |grad| (same seed => same masks)
     p = model.up_blocks[8].Conv_1.weight
     torch.manual_seed(11); model.zero_grad(); loss_fn(model, batch, class_labels=labels).backward()
