@@ -227,20 +227,62 @@ struct SgemmArgs {
     const float* B; long b_k, b_n; int b_act;
     float* C; long c_m, c_n; int accumulate;
     int M, N, K;
+    int no_split;   // C is not pre-zeroed: keep K in one workgroup
 };
+// C[M][N] (+)= act(A)[M][K] * act(B)[K][N], any strides.  64x64 output tile per workgroup (4 waves x 2x2 MFMA tiles),
+// K split over blockIdx.z (atomics when split or accumulating; the caller zeroes C first in that case).
 __global__ __launch_bounds__(RDMI_THREADS) void small_gemm_kernel(SgemmArgs a) {
-    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
-    if (i >= (long)a.M * a.N) return;
-    const int m = (int)(i / a.N), n = (int)(i - (long)m * a.N);
-    float s = 0.f;
-    for (int k = 0; k < a.K; ++k) {
-        float x = a.A[m * a.a_m + k * a.a_k], y = a.B[k * a.b_k + n * a.b_n];
-        if (a.a_act) x = silu_f(x);
-        if (a.b_act) y = silu_f(y);
-        s += x * y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 64 + (wave >> 1) * 32, n0 = blockIdx.y * 64 + (wave & 1) * 32;
+    const int kc = (a.K + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kb = blockIdx.z * kc, ke = min(a.K, kb + kc);
+    f32x4 acc[2][2] = {};
+    long ao[2], bo[2];
+    bool av[2], bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 16 + col, n = n0 + i * 16 + col;
+        av[i] = m < a.M; bv[i] = n < a.N;
+        ao[i] = (long)min(m, a.M - 1) * a.a_m;
+        bo[i] = (long)min(n, a.N - 1) * a.b_n;
     }
-    float* c = a.C + m * a.c_m + n * a.c_n;
-    *c = a.accumulate ? *c + s : s;
+    for (int k = kb; k < ke; k += 4) {
+        const int kk = k + kq;
+        const bool kv = kk < ke;
+        const long ka = (long)min(kk, ke - 1);
+        float x[2], y[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            x[i] = ldg1(a.A + ao[i] + ka * a.a_k);
+            y[i] = ldg1(a.B + bo[i] + ka * a.b_k);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (a.a_act) x[i] = silu_f(x[i]);
+            if (a.b_act) y[i] = silu_f(y[i]);
+            x[i] = (kv && av[i]) ? x[i] : 0.f;
+            y[i] = (kv && bv[i]) ? y[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(x[i], y[j], acc[i][j]);
+    }
+    const bool atomic = a.accumulate || gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + kq * 4 + r, n = n0 + j * 16 + col;
+                if (m < a.M && n < a.N) {
+                    float* c = a.C + (long)m * a.c_m + (long)n * a.c_n;
+                    if (atomic) atomicAdd(c, acc[i][j][r]);
+                    else *c = acc[i][j][r];
+                }
+            }
 }
 
 // g <- g * silu'(x)
@@ -254,11 +296,17 @@ __global__ __launch_bounds__(RDMI_THREADS) void silu_bwd_kernel(float* __restric
 // out[c] (+)= sum_m X[m][c]    (bias gradients of the embedding layers)
 __global__ __launch_bounds__(RDMI_THREADS) void colsum2d_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int C,
                                                                  int ldx) {
-    const int c = blockIdx.x * RDMI_THREADS + threadIdx.x;
-    if (c >= C) return;
+    // grid (C/64, row slabs): 4 row lanes x 64 columns per workgroup, LDS reduce, one atomic per column and slab
+    __shared__ float red[RDMI_THREADS];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    const int per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int mb = blockIdx.y * per, me = min(M, mb + per);
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += X[(size_t)m * ldx + c];
-    out[c] += s;
+    if (c < C)
+        for (int m = mb + r; m < me; m += 4) s += X[(size_t)m * ldx + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (r == 0 && c < C) atomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // Fourier features of log(sigma) materialised for the time_mlp.0 weight gradient: F[m][0:nf] = sin, [nf:2nf] = cos
@@ -271,10 +319,13 @@ __global__ __launch_bounds__(RDMI_THREADS) void fourier_kernel(const float* __re
     F[i] = k < nf ? sinf(arg) : cosf(arg);
 }
 
-// AttnBlockpp backward, one sample per workgroup, plain fp32 loops over LDS-resident tensors (C = 64, L <= 96).
+// AttnBlockpp backward on the fp32 MFMA (C = 64, L <= 96).  A workgroup (8 waves) walks samples blockIdx.x, +gridDim.x, ...
+// with every tensor of one sample in LDS ([L][C+4] / [L][L+4] rows), and keeps the four NIN weight gradients as MFMA
+// accumulators across its samples (one atomic pass at the end instead of one per sample).
 // Recomputes xn, q, k, v, P, O from x, then:  gH = s*gOut;  dW3 += O^T gH; gO = gH W3^T;  gP = gO V^T; gV = P^T gO;
 // gS = P * (gP - rowsum(gP * P)) / sqrt(C);  gQ = gS K; gK = gS^T Q;  dWq/k/v += xn^T g{Q,K,V};  gxn = sum g. W^T;
 // GroupNorm backward (no activation) -> gx;  gX += gx + gH (residual branch).
+#define AB_THREADS 512
 struct AttnBwdArgs {
     const float* x; const float* gOut; float* gX;
     const float* gamma; const float* beta; float* dgamma; float* dbeta;
@@ -284,160 +335,279 @@ struct AttnBwdArgs {
 };
 
 template <int C>
-__host__ __device__ inline size_t attn_bwd_lds_bytes(int L, int G) { return ((size_t)5 * L * C + (size_t)2 * L * L + 4 * G) * 4; }
+__host__ __device__ inline size_t attn_bwd_lds_bytes(int L, int G) {
+    const int LD = C + 4, LP = L + 4;
+    const size_t big = (size_t)L * (LP > LD ? LP : LD);
+    return ((size_t)4 * L * LD + 2 * big + 4 * G + 2 * C + 2 * (AB_THREADS / 64) * G + 8 * C) * 4;
+}
+
+// one 16x16 output tile: acc += sum_k A(m, k) B(k, n) for this lane's (m or n) = tile*16 + (lane & 15), k = 4*step + (lane >> 4)
+template <class FA, class FB>
+__device__ __forceinline__ f32x4 ab_tile(int steps, int kq, FA fa, FB fb, f32x4 acc) {
+#pragma unroll 4
+    for (int k = 0; k < steps; ++k) acc = mfma16(fa(4 * k + kq), fb(4 * k + kq), acc);
+    return acc;
+}
 
 template <int C>
-__global__ __launch_bounds__(RDMI_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
-    const int tid = threadIdx.x, n = blockIdx.x, L = a.L;
-    constexpr int NPT = (96 * C + RDMI_THREADS - 1) / RDMI_THREADS;     // elements of an [L][C] tensor per work-item
-    float* XH = reinterpret_cast<float*>(rdmi_lds);  // [L][C] raw x, then xhat
-    float* Q = XH + L * C; float* K = Q + L * C; float* V = K + L * C;
-    float* O = V + L * C;                            // attention output -> gO -> gV
-    float* P = O + L * C;                            // [L][L]
-    float* GP = P + L * L;                           // [L][L] gP -> gS
-    float* stat = GP + L * L;                        // [G][4]
-    const float* xg = a.x + (size_t)n * L * C;
-    const float* gog = a.gOut + (size_t)n * L * C;   // gH(p, c) = gog[p*C + c] * out_scale (re-read from L2 when needed)
-    for (int i = tid; i < L * C; i += RDMI_THREADS) XH[i] = xg[i];
-    __syncthreads();
-    const int G = a.G, Cg = C / G, cnt = Cg * L;
-    if (tid < G) {
-        float s = 0.f;
-        for (int e = 0; e < cnt; ++e) s += XH[(e / Cg) * C + tid * Cg + e % Cg];
-        const float mean = s / (float)cnt;
-        float q = 0.f;
-        for (int e = 0; e < cnt; ++e) { const float d = XH[(e / Cg) * C + tid * Cg + e % Cg] - mean; q += d * d; }
-        stat[4 * tid] = mean; stat[4 * tid + 1] = 1.0f / sqrtf(q / (float)cnt + a.eps);
-    }
-    __syncthreads();
-    for (int i = tid; i < L * C; i += RDMI_THREADS) { const int g = (i % C) / Cg; XH[i] = (XH[i] - stat[4 * g]) * stat[4 * g + 1]; }
-    __syncthreads();
-#define XN_(p, j) (XH[(p) * C + (j)] * a.gamma[j] + a.beta[j])
-    // q, k, v
-    for (int i = tid; i < L * C; i += RDMI_THREADS) {
-        const int p = i / C, c = i - p * C;
-        float q = a.b[0][c], k = a.b[1][c], v = a.b[2][c];
-        for (int j = 0; j < C; ++j) { const float xv = XN_(p, j); q += xv * a.W[0][j * C + c]; k += xv * a.W[1][j * C + c]; v += xv * a.W[2][j * C + c]; }
-        Q[i] = q; K[i] = k; V[i] = v;
-    }
-    __syncthreads();
-    // P = softmax(Q K^T * scale): one row per work-item
-    for (int r = tid; r < L; r += RDMI_THREADS) {
-        float mx = -3.0e38f;
-        for (int j = 0; j < L; ++j) { float s = 0.f; for (int c = 0; c < C; ++c) s += Q[r * C + c] * K[j * C + c]; s *= a.scale; P[r * L + j] = s; mx = fmaxf(mx, s); }
-        float sum = 0.f;
-        for (int j = 0; j < L; ++j) { const float e = __expf(P[r * L + j] - mx); P[r * L + j] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < L; ++j) P[r * L + j] *= inv;
-    }
-    __syncthreads();
-    for (int i = tid; i < L * C; i += RDMI_THREADS) {
-        const int p = i / C, c = i - p * C;
-        float o = 0.f;
-        for (int j = 0; j < L; ++j) o += P[p * L + j] * V[j * C + c];
-        O[i] = o;
-    }
-    __syncthreads();
-    // NIN_3: dW3[j][c] += sum_p O[p][j] gH[p][c]; db3[c] += sum_p gH[p][c]
-    for (int i = tid; i < C * C; i += RDMI_THREADS) {
-        const int j = i / C, c = i - j * C;
-        float s = 0.f;
-        for (int p = 0; p < L; ++p) s += O[p * C + j] * (gog[p * C + c] * a.out_scale);
-        atomicAdd(a.dW[3] + i, s);
-    }
-    if (tid < C) { float s = 0.f; for (int p = 0; p < L; ++p) s += gog[p * C + tid] * a.out_scale; atomicAdd(a.db[3] + tid, s); }
-    __syncthreads();
-    // O <- gO[p][j] = sum_c gH[p][c] W3[j][c]
-    for (int i = tid; i < L * C; i += RDMI_THREADS) {
-        const int p = i / C, j = i - p * C;
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += (gog[p * C + c] * a.out_scale) * a.W[3][j * C + c];
-        O[i] = s;
-    }
-    __syncthreads();
-    // gP[r][j] = sum_c gO[r][c] V[j][c]
-    for (int i = tid; i < L * L; i += RDMI_THREADS) {
-        const int r = i / L, j = i - r * L;
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += O[r * C + c] * V[j * C + c];
-        GP[i] = s;
-    }
-    // gV[j][c] = sum_r P[r][j] gO[r][c]   (held in registers until gO is dead)
-    float gv[NPT];
-    {
-        int m = 0;
-        for (int i = tid; i < L * C; i += RDMI_THREADS) {
-            const int j = i / C, c = i - j * C;
-            float s = 0.f;
-            for (int r = 0; r < L; ++r) s += P[r * L + j] * O[r * C + c];
-            gv[m++] = s;
-        }
-    }
-    __syncthreads();
-    // gS = P * (gP - rowsum(gP * P)) * scale, in place over GP;  O <- gV
-    for (int r = tid; r < L; r += RDMI_THREADS) {
-        float d = 0.f;
-        for (int j = 0; j < L; ++j) d += GP[r * L + j] * P[r * L + j];
-        for (int j = 0; j < L; ++j) GP[r * L + j] = P[r * L + j] * (GP[r * L + j] - d) * a.scale;
-    }
-    {
-        int m = 0;
-        for (int i = tid; i < L * C; i += RDMI_THREADS) O[i] = gv[m++];
-    }
-    __syncthreads();
-    // gQ[r][c] = sum_j gS[r][j] K[j][c];  gK[r][c] = sum_j gS[j][r] Q[j][c]   (registers, then overwrite Q, K)
-    {
-        float gq[NPT], gk[NPT];
-        int m = 0;
-        for (int i = tid; i < L * C; i += RDMI_THREADS) {
-            const int r = i / C, c = i - r * C;
-            float s1 = 0.f, s2 = 0.f;
-            for (int j = 0; j < L; ++j) { s1 += GP[r * L + j] * K[j * C + c]; s2 += GP[j * L + r] * Q[j * C + c]; }
-            gq[m] = s1; gk[m] = s2; ++m;
+__global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
+    static_assert(C == 64, "lane == channel below");
+    constexpr int NW = AB_THREADS / 64, LD = C + 4, CT = C / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    const int L = a.L, LP = L + 4, MT = (L + 15) >> 4, KL = (L + 3) >> 2, G = a.G, Cg = C / G;
+    const float cnt = (float)(Cg * L);
+    const int big = L * (LP > LD ? LP : LD);
+    float* Q = reinterpret_cast<float*>(rdmi_lds);
+    float* K = Q + L * LD; float* V = K + L * LD; float* O = V + L * LD;
+    float* P = O + L * LD;            // [L][LP] probabilities; later xhat [L][LD]
+    float* GP = P + big;              // gH [L][LD]; later gP -> gS [L][LP]
+    float* stat = GP + big;           // [G][4] mean, rstd, m1, m2
+    float* gam = stat + 4 * G; float* bet = gam + C;
+    float* red = bet + C;             // [NW][G][2]
+    float* cred = red + 2 * NW * G;   // [8][C] column reductions at the very end
+    if (tid < C) { gam[tid] = a.gamma[tid]; bet[tid] = a.beta[tid]; }
+    f32x4 dw3[2] = {}, dw012[6] = {};
+    float dbq = 0.f, dbk = 0.f, dbv = 0.f, dbh = 0.f, dgm = 0.f, dbt = 0.f;   // this work-item's channel = lane
+
+    // group reduction of two per-work-item partials (channel = lane, so a group is Cg neighbouring lanes)
+    auto group_reduce = [&](float u, float v, int slot) {
+        for (int off = 1; off < Cg; off <<= 1) { u += __shfl_xor(u, off); v += __shfl_xor(v, off); }
+        if ((lane & (Cg - 1)) == 0) { red[(wave * G + lane / Cg) * 2] = u; red[(wave * G + lane / Cg) * 2 + 1] = v; }
+        __syncthreads();
+        if (tid < G) {
+            float su = 0.f, sv = 0.f;
+            for (int w = 0; w < NW; ++w) { su += red[(w * G + tid) * 2]; sv += red[(w * G + tid) * 2 + 1]; }
+            stat[4 * tid + slot] = su; stat[4 * tid + slot + 1] = sv;
         }
         __syncthreads();
-        m = 0;
-        for (int i = tid; i < L * C; i += RDMI_THREADS) { Q[i] = gq[m]; K[i] = gk[m]; ++m; }
+    };
+
+    for (int n = blockIdx.x; n < a.NB; n += gridDim.x) {
+        const float* xg = a.x + (size_t)n * L * C;
+        const float* gog = a.gOut + (size_t)n * L * C;
+        // ---- stage x (-> O) and gH (-> GP); GroupNorm statistics; O <- xn
+        for (int p = wave; p < L; p += NW) { O[p * LD + lane] = ldg1(xg + p * C + lane); GP[p * LD + lane] = ldg1(gog + p * C + lane) * a.out_scale; }
+        {
+            float s1 = 0.f;
+            for (int p = wave; p < L; p += NW) s1 += O[p * LD + lane];
+            group_reduce(s1, 0.f, 0);
+            const float mean = stat[4 * (lane / Cg)] / cnt;
+            float s2 = 0.f;
+            for (int p = wave; p < L; p += NW) { const float d = O[p * LD + lane] - mean; s2 += d * d; }
+            __syncthreads();                                   // everyone has read the sum before slot 0/1 are rewritten
+            group_reduce(s2, 0.f, 2);
+            if (tid < G) { const float m = stat[4 * tid] / cnt; stat[4 * tid + 1] = 1.0f / sqrtf(stat[4 * tid + 2] / cnt + a.eps); stat[4 * tid] = m; }
+            __syncthreads();
+            const float m = stat[4 * (lane / Cg)], rs = stat[4 * (lane / Cg) + 1];
+            for (int p = wave; p < L; p += NW) O[p * LD + lane] = (O[p * LD + lane] - m) * rs * gam[lane] + bet[lane];
+        }
+        __syncthreads();
+        // ---- A: q, k, v = xn W + b
+        for (int t = wave; t < 3 * MT * CT; t += NW) {
+            const int which = t / (MT * CT), r = t - which * MT * CT, mt = r / CT, nt = r - mt * CT;
+            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col;
+            const float* W = a.W[which];
+            f32x4 acc = ab_tile(C / 4, kq, [&](int k) { return O[m * LD + k]; }, [&](int k) { return ldg1(W + k * C + nn); }, f32x4{0.f, 0.f, 0.f, 0.f});
+            float* dst = which == 0 ? Q : which == 1 ? K : V;
+            const float bias = ldg1(a.b[which] + nn);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) dst[mm * LD + nn] = acc[r4] + bias; }
+        }
+        __syncthreads();
+        // ---- B: P = softmax(Q K^T * scale)
+        for (int t = wave; t < MT * MT; t += NW) {
+            const int mt = t / MT, nt = t - mt * MT;
+            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col, nc = min(nn, L - 1);
+            f32x4 acc = ab_tile(C / 4, kq, [&](int k) { return Q[m * LD + k]; }, [&](int k) { return K[nc * LD + k]; }, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L && nn < L) P[mm * LP + nn] = acc[r4] * a.scale; }
+        }
+        __syncthreads();
+        for (int r = wave; r < L; r += NW) {
+            const float s0 = lane < L ? P[r * LP + lane] : -3.0e38f, s1 = lane + 64 < L ? P[r * LP + lane + 64] : -3.0e38f;
+            float mx = fmaxf(s0, s1);
+            for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            const float e0 = lane < L ? __expf(s0 - mx) : 0.f, e1 = lane + 64 < L ? __expf(s1 - mx) : 0.f;
+            float sum = e0 + e1;
+            for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
+            const float inv = 1.0f / sum;
+            if (lane < L) P[r * LP + lane] = e0 * inv;
+            if (lane + 64 < L) P[r * LP + lane + 64] = e1 * inv;
+        }
+        __syncthreads();
+        // ---- C: O = P V
+        for (int t = wave; t < MT * CT; t += NW) {
+            const int mt = t / CT, nt = t - mt * CT;
+            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col;
+            f32x4 acc = ab_tile(KL, kq, [&](int k) { return k < L ? P[m * LP + k] : 0.f; }, [&](int k) { return k < L ? V[k * LD + nn] : 0.f; },
+                                f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) O[mm * LD + nn] = acc[r4]; }
+        }
+        __syncthreads();
+        // ---- D: dW3 += O^T gH;  gO = gH W3^T (registers, then over O)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave * 2 + i, jt = t / CT, ct = t - jt * CT;
+            const int j = jt * 16 + col, cc = ct * 16 + col;
+            dw3[i] = ab_tile(KL, kq, [&](int k) { return k < L ? O[k * LD + j] : 0.f; }, [&](int k) { return k < L ? GP[k * LD + cc] : 0.f; }, dw3[i]);
+        }
+        for (int p = wave; p < L; p += NW) dbh += GP[p * LD + lane];
+        f32x4 hold[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = wave + i * NW;
+            hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < MT * CT) {
+                const int mt = t / CT, nt = t - mt * CT;
+                const int m = min(mt * 16 + col, L - 1), j = nt * 16 + col;
+                const float* W3 = a.W[3];
+                hold[i] = ab_tile(C / 4, kq, [&](int k) { return GP[m * LD + k]; }, [&](int k) { return ldg1(W3 + j * C + k); }, hold[i]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = wave + i * NW;
+            if (t < MT * CT) {
+                const int mt = t / CT, nt = t - mt * CT, j = nt * 16 + col;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) O[mm * LD + j] = hold[i][r4]; }
+            }
+        }
+        __syncthreads();
+        // ---- E: gP = gO V^T -> GP (gH is dead);  gV = P^T gO -> registers
+        for (int t = wave; t < MT * MT; t += NW) {
+            const int mt = t / MT, nt = t - mt * MT;
+            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col, nc = min(nn, L - 1);
+            f32x4 acc = ab_tile(C / 4, kq, [&](int k) { return O[m * LD + k]; }, [&](int k) { return V[nc * LD + k]; }, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L && nn < L) GP[mm * LP + nn] = acc[r4]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = wave + i * NW;
+            hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < MT * CT) {
+                const int mt = t / CT, nt = t - mt * CT;
+                const int j = min(mt * 16 + col, L - 1), cc = nt * 16 + col;
+                hold[i] = ab_tile(KL, kq, [&](int k) { return k < L ? P[k * LP + j] : 0.f; }, [&](int k) { return k < L ? O[k * LD + cc] : 0.f; }, hold[i]);
+            }
+        }
+        __syncthreads();
+        // ---- F: gS = P * (gP - rowsum(gP * P)) * scale over GP;  O <- gV
+        for (int r = wave; r < L; r += NW) {
+            const float p0 = lane < L ? P[r * LP + lane] : 0.f, p1 = lane + 64 < L ? P[r * LP + lane + 64] : 0.f;
+            const float g0 = lane < L ? GP[r * LP + lane] : 0.f, g1 = lane + 64 < L ? GP[r * LP + lane + 64] : 0.f;
+            float d = p0 * g0 + p1 * g1;
+            for (int off = 32; off; off >>= 1) d += __shfl_xor(d, off);
+            if (lane < L) GP[r * LP + lane] = p0 * (g0 - d) * a.scale;
+            if (lane + 64 < L) GP[r * LP + lane + 64] = p1 * (g1 - d) * a.scale;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t = wave + i * NW;
+            if (t < MT * CT) {
+                const int mt = t / CT, nt = t - mt * CT, cc = nt * 16 + col;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) O[mm * LD + cc] = hold[i][r4]; }
+            }
+        }
+        __syncthreads();
+        // ---- G: gQ = gS K, gK = gS^T Q -> registers;  P region <- xhat
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int t = wave + i * NW;
+            hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < 2 * MT * CT) {
+                const int which = t / (MT * CT), r = t - which * MT * CT, mt = r / CT, nt = r - mt * CT;
+                const int m = min(mt * 16 + col, L - 1), cc = nt * 16 + col;
+                if (which == 0) hold[i] = ab_tile(KL, kq, [&](int k) { return k < L ? GP[m * LP + k] : 0.f; }, [&](int k) { return k < L ? K[k * LD + cc] : 0.f; }, hold[i]);
+                else hold[i] = ab_tile(KL, kq, [&](int k) { return k < L ? GP[k * LP + m] : 0.f; }, [&](int k) { return k < L ? Q[k * LD + cc] : 0.f; }, hold[i]);
+            }
+        }
+        {
+            const float m = stat[4 * (lane / Cg)], rs = stat[4 * (lane / Cg) + 1];
+            for (int p = wave; p < L; p += NW) P[p * LD + lane] = (ldg1(xg + p * C + lane) - m) * rs;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int t = wave + i * NW;
+            if (t < 2 * MT * CT) {
+                const int which = t / (MT * CT), r = t - which * MT * CT, mt = r / CT, nt = r - mt * CT, cc = nt * 16 + col;
+                float* dst = which == 0 ? Q : K;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) dst[mm * LD + cc] = hold[i][r4]; }
+            }
+        }
+        __syncthreads();
+        // ---- H: Q = gQ, K = gK, O = gV.  dW0..2 += xn^T g.;  bias partials;  V <- gxn = gQ W0^T + gK W1^T + gV W2^T
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int t = wave * 6 + i, which = t / (CT * CT), r = t - which * CT * CT, jt = r / CT, ct = r - jt * CT;
+            const int j = jt * 16 + col, cc = ct * 16 + col;
+            const float gj = gam[j], bj = bet[j];
+            const float* src = which == 0 ? Q : which == 1 ? K : O;
+            dw012[i] = ab_tile(KL, kq, [&](int k) { return k < L ? P[k * LD + j] * gj + bj : 0.f; }, [&](int k) { return k < L ? src[k * LD + cc] : 0.f; }, dw012[i]);
+        }
+        for (int p = wave; p < L; p += NW) { dbq += Q[p * LD + lane]; dbk += K[p * LD + lane]; dbv += O[p * LD + lane]; }
+        for (int t = wave; t < MT * CT; t += NW) {
+            const int mt = t / CT, nt = t - mt * CT;
+            const int m = min(mt * 16 + col, L - 1), j = nt * 16 + col;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ab_tile(C / 4, kq, [&](int k) { return Q[m * LD + k]; }, [&](int k) { return ldg1(a.W[0] + j * C + k); }, acc);
+            acc = ab_tile(C / 4, kq, [&](int k) { return K[m * LD + k]; }, [&](int k) { return ldg1(a.W[1] + j * C + k); }, acc);
+            acc = ab_tile(C / 4, kq, [&](int k) { return O[m * LD + k]; }, [&](int k) { return ldg1(a.W[2] + j * C + k); }, acc);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) V[mm * LD + j] = acc[r4]; }
+        }
+        __syncthreads();
+        // ---- J: GroupNorm backward (no activation), residual branch
+        {
+            float u = 0.f, v = 0.f;
+            for (int p = wave; p < L; p += NW) {
+                const float gy = V[p * LD + lane], xh = P[p * LD + lane];
+                dgm += gy * xh; dbt += gy;
+                const float gxh = gy * gam[lane];
+                u += gxh; v += gxh * xh;
+            }
+            group_reduce(u, v, 2);
+            const int g = lane / Cg;
+            const float rs = stat[4 * g + 1], m1 = stat[4 * g + 2] / cnt, m2 = stat[4 * g + 3] / cnt;
+            float* gxo = a.gX + (size_t)n * L * C;
+            for (int p = wave; p < L; p += NW) {
+                const float gxh = V[p * LD + lane] * gam[lane];
+                gxo[p * C + lane] += rs * (gxh - m1 - P[p * LD + lane] * m2) + ldg1(gog + p * C + lane) * a.out_scale;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // now Q = gQ, K = gK, O = gV.  Weight/bias gradients of NIN_0..2
-    for (int i = tid; i < C * C; i += RDMI_THREADS) {
-        const int j = i / C, c = i - j * C;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int p = 0; p < L; ++p) { const float xv = XN_(p, j); s0 += xv * Q[p * C + c]; s1 += xv * K[p * C + c]; s2 += xv * O[p * C + c]; }
-        atomicAdd(a.dW[0] + i, s0); atomicAdd(a.dW[1] + i, s1); atomicAdd(a.dW[2] + i, s2);
+    // ---- flush the per-workgroup parameter gradients
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = wave * 2 + i, jt = t / CT, ct = t - jt * CT;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) atomicAdd(a.dW[3] + (jt * 16 + kq * 4 + r4) * C + ct * 16 + col, dw3[i][r4]);
     }
-    if (tid < C) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int p = 0; p < L; ++p) { s0 += Q[p * C + tid]; s1 += K[p * C + tid]; s2 += O[p * C + tid]; }
-        atomicAdd(a.db[0] + tid, s0); atomicAdd(a.db[1] + tid, s1); atomicAdd(a.db[2] + tid, s2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int t = wave * 6 + i, which = t / (CT * CT), r = t - which * CT * CT, jt = r / CT, ct = r - jt * CT;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) atomicAdd(a.dW[which] + (jt * 16 + kq * 4 + r4) * C + ct * 16 + col, dw012[i][r4]);
     }
-    // V <- gy[p][j] = gxn = sum_c gQ W0[j][c] + gK W1[j][c] + gV W2[j][c]   (GroupNorm here has no activation)
-    for (int i = tid; i < L * C; i += RDMI_THREADS) {
-        const int p = i / C, j = i - p * C;
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += Q[p * C + c] * a.W[0][j * C + c] + K[p * C + c] * a.W[1][j * C + c] + O[p * C + c] * a.W[2][j * C + c];
-        V[i] = s;
+    float* outs[6] = {a.db[0], a.db[1], a.db[2], a.db[3], a.dgamma, a.dbeta};
+    const float vals[6] = {dbq, dbk, dbv, dbh, dgm, dbt};
+    for (int q = 0; q < 6; ++q) {
+        __syncthreads();
+        cred[wave * C + lane] = vals[q];
+        __syncthreads();
+        if (tid < C) {
+            float sum = 0.f;
+            for (int w = 0; w < NW; ++w) sum += cred[w * C + tid];
+            atomicAdd(outs[q] + tid, sum);
+        }
     }
-    __syncthreads();
-    if (tid < C) {
-        float dg = 0.f, dbt = 0.f;
-        for (int p = 0; p < L; ++p) { dg += V[p * C + tid] * XH[p * C + tid]; dbt += V[p * C + tid]; }
-        atomicAdd(a.dgamma + tid, dg); atomicAdd(a.dbeta + tid, dbt);
-    }
-    if (tid < G) {
-        float m1 = 0.f, m2 = 0.f;
-        for (int e = 0; e < cnt; ++e) { const int p = e / Cg, c = tid * Cg + e % Cg; const float gxh = V[p * C + c] * a.gamma[c]; m1 += gxh; m2 += gxh * XH[p * C + c]; }
-        stat[4 * tid + 2] = m1 / (float)cnt; stat[4 * tid + 3] = m2 / (float)cnt;
-    }
-    __syncthreads();
-    float* gxo = a.gX + (size_t)n * L * C;
-    for (int i = tid; i < L * C; i += RDMI_THREADS) {
-        const int c = i % C, g = c / Cg;
-        const float gxh = V[i] * a.gamma[c];
-        gxo[i] += stat[4 * g + 1] * (gxh - stat[4 * g + 2] - XH[i] * stat[4 * g + 3]) + gog[i] * a.out_scale;
-    }
-#undef XN_
 }
 
 // loss backward: gscore[i] = gper[b] * dper_dscore[i]

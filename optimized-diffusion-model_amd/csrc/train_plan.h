@@ -49,7 +49,11 @@ namespace {
 std::map<rdmi_ctx*, TrainPlan*>& train_registry() { static std::map<rdmi_ctx*, TrainPlan*> r; return r; }
 
 int launch_small_gemm(const SgemmArgs& g, hipStream_t s) {
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(g.M * g.N, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, g);
+    // weight-gradient shapes contract over the batch: split K so that ~1024 workgroups are in flight
+    const int tiles = ceil_div(g.M, 64) * ceil_div(g.N, 64);
+    int ks = 1;
+    if (!g.no_split) ks = std::max(1, std::min(ceil_div(g.K, 64), 1024 / tiles));
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(g.M, 64), (unsigned)ceil_div(g.N, 64), (unsigned)ks), dim3(RDMI_THREADS), 0, s, g);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -302,7 +306,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
                 a.W[k] = c->params[(size_t)pw].ptr; a.b[k] = c->params[(size_t)pb].ptr; a.dW[k] = pgrad(pw); a.db[k] = pgrad(pb);
             }
             a.NB = NB; a.L = op.attn.L; a.G = op.attn.G; a.eps = op.attn.eps; a.scale = op.attn.scale; a.out_scale = op.attn.out_scale;
-            hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3((unsigned)NB), dim3(RDMI_THREADS), attn_bwd_lds_bytes<64>(a.L, a.G), s, a);
+            hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3((unsigned)std::min(NB, 256)), dim3(AB_THREADS), attn_bwd_lds_bytes<64>(a.L, a.G), s, a);
             HIP_OK(hipGetLastError());
             continue;
         }
@@ -403,10 +407,10 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.B = c->d_temb; g.b_k = Tm; g.b_n = 1; g.b_act = 1;
             g.C = pgrad(pw); g.c_m = Tm; g.c_n = 1; g.accumulate = 0; g.M = bl.second; g.N = Tm; g.K = NB;
             if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(bl.second, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)(T.gdense + off), pgrad(pb), NB, bl.second, DT);
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(bl.second, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)(T.gdense + off), pgrad(pb), NB, bl.second, DT);
             SgemmArgs h{};   // gta[n][k] (+)= sum_co gdense[n][off+co] * Wd[co][k]
             h.A = T.gdense + off; h.a_m = DT; h.a_k = 1; h.B = c->params[(size_t)pw].ptr; h.b_k = Tm; h.b_n = 1;
-            h.C = T.gta; h.c_m = Tm; h.c_n = 1; h.accumulate = first ? 0 : 1; h.M = NB; h.N = Tm; h.K = bl.second;
+            h.C = T.gta; h.c_m = Tm; h.c_n = 1; h.accumulate = first ? 0 : 1; h.M = NB; h.N = Tm; h.K = bl.second; h.no_split = 1;
             if (int e = launch_small_gemm(h, s)) return e;
             first = false;
             off += bl.second;
@@ -419,7 +423,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.A = T.gta; g.a_m = 1; g.a_k = Tm; g.B = T.lab_copy; g.b_k = nc; g.b_n = 1; g.C = pgrad(pw); g.c_m = nc; g.c_n = 1;
             g.M = Tm; g.N = nc; g.K = NB;
             if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
         }
         {
             const int pw = c->pindex.at("time_mlp.2.weight"), pb = c->pindex.at("time_mlp.2.bias");
@@ -427,10 +431,10 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.A = T.gta; g.a_m = 1; g.a_k = Tm; g.B = c->d_h1; g.b_k = Tm; g.b_n = 1; g.b_act = 1; g.C = pgrad(pw); g.c_m = Tm; g.c_n = 1;
             g.M = Tm; g.N = Tm; g.K = NB;
             if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
             SgemmArgs h{};   // gh1[n][j] = sum_k gtemb[n][k] * W2[k][j]
             h.A = T.gta; h.a_m = Tm; h.a_k = 1; h.B = c->params[(size_t)pw].ptr; h.b_k = Tm; h.b_n = 1; h.C = T.gh1; h.c_m = Tm; h.c_n = 1;
-            h.M = NB; h.N = Tm; h.K = Tm;
+            h.M = NB; h.N = Tm; h.K = Tm; h.no_split = 1;
             if (int e = launch_small_gemm(h, s)) return e;
             hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)ceil_div(NB * Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, T.gh1, (const float*)c->d_h1, (long)NB * Tm);
         }
@@ -442,7 +446,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.A = T.gh1; g.a_m = 1; g.a_k = Tm; g.B = T.four; g.b_k = 2 * nf; g.b_n = 1; g.C = pgrad(pw); g.c_m = 2 * nf; g.c_n = 1;
             g.M = Tm; g.N = 2 * nf; g.K = NB;
             if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.gh1, pgrad(pb), NB, Tm, Tm);
+            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)T.gh1, pgrad(pb), NB, Tm, Tm);
         }
         HIP_OK(hipGetLastError());
     }
