@@ -170,53 +170,151 @@ __global__ __launch_bounds__(RDMI_THREADS) void scatter_grad_kernel(const float*
 
 // Weight gradient: dW[co][ci][tap] (reference OIHW layout, or NIN [ci][co] / Linear [co][ci] through the strides)
 //   += sum_{n, o} ACT[n][in(o, tap)][ci] * G[n][o][co]
-// grid = (ntap * ksplit, ceil(Cin/32), ceil(Cout/32)): a workgroup owns a 32x32 (ci x co) tile of one tap for a slice of
-// the samples (split-K over the batch, partial tiles merged with fp32 atomics); wave w owns the 16x16 sub-tile
-// (w&1, w>>1) and contracts over (sample, output pixel) with MFMA 16x16x4, eight k-steps of loads in flight per iteration.
+// grid = (ksplit, ceil(Cin/32), ceil(Cout/64)).  A workgroup owns the 32(ci) x 64(co) tile of ALL taps for a slice of the
+// samples (split-K over the batch, merged with fp32 atomics).  Per chunk of S samples it stages the ACT rows [S*HWv][32]
+// and the G rows [S*HWo][64] in LDS (register-prefetched one chunk ahead); the taps are row-offset views of the staged
+// ACT through a byte table (out-of-image -> a zero row), so one G fragment feeds NTAP MFMAs.  Wave w: ci half w&1,
+// co half w>>1, accumulators [NTAP][2].
 struct WgradArgs {
     const float* ACT; const float* G; float* dW;
     const int* tab;        // [HWo][ntap] input pixel of (output pixel, tap) or -1   (null: identity, 1 tap)
     int NB, HWv, HWo, Cin, Cout, ntap;
-    int lda;               // channels per pixel of ACT (>= Cin: padded input channels)
+    int lda;               // channels per pixel of ACT (>= Cin: padded input channels; multiple of 4)
     int ksplit;            // number of sample slices
+    int S;                 // samples per staged chunk: S*HWv <= 255, S*HWo <= 128
     long s_co, s_ci, s_t;  // strides of dW
 };
+#define WG_AS 40
+#define WG_GS 72
+__host__ __device__ inline int wgrad_chunk(int HWv, int HWo) {
+    int s = 128 / HWo; if (255 / HWv < s) s = 255 / HWv;
+    return s < 1 ? 1 : s;
+}
+__host__ __device__ inline size_t wgrad_lds_bytes(int HWv, int HWo, int S) {
+    const int RI = S * HWv, RO4 = (S * HWo + 3) & ~3;
+    const size_t stage = (size_t)(RI + 1) * WG_AS + (size_t)RO4 * WG_GS + (size_t)RO4 * 4, flush = (size_t)64 * (32 * 9 + 1);
+    return (stage > flush ? stage : flush) * 4;
+}
 
+template <int NTAP>
 __global__ __launch_bounds__(RDMI_THREADS) void wgrad_mfma_kernel(WgradArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lrow = lane & 15, kq = lane >> 4;
-    const int tap = blockIdx.x % a.ntap, slice = blockIdx.x / a.ntap;
-    int* vt = reinterpret_cast<int*>(rdmi_lds);                  // [HWo4] input pixel of each output pixel for this tap (-1: none)
-    const int HWo4 = (a.HWo + 3) & ~3;
-    for (int o = threadIdx.x; o < HWo4; o += RDMI_THREADS) vt[o] = o < a.HWo ? (a.tab ? a.tab[o * a.ntap + tap] : o) : -1;
-    __syncthreads();
-    const int ci = blockIdx.y * 32 + (wave & 1) * 16 + lrow;      // A row  (this lane's input channel)
-    const int co = blockIdx.z * 32 + (wave >> 1) * 16 + lrow;     // B col  (this lane's output channel)
-    const bool ci_ok = ci < a.Cin, co_ok = co < a.Cout;
-    const int per = (a.NB + a.ksplit - 1) / a.ksplit;
-    const int n_lo = slice * per, n_hi = min(a.NB, n_lo + per);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;                                          // k-steps (of 4 pixels) per unrolled iteration
-    for (int n = n_lo; n < n_hi; ++n) {
-        const float* An = a.ACT + (size_t)n * a.HWv * a.lda + ci;
-        const float* Gn = a.G + (size_t)n * a.HWo * a.Cout + co;
-        for (int o0 = 0; o0 < HWo4; o0 += 4 * U) {
-            float av[U], bv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int o = o0 + 4 * u + kq;
-                const int v = o < HWo4 ? vt[o] : -1;
-                av[u] = (v >= 0 && ci_ok) ? ldg1(An + (size_t)v * a.lda) : 0.f;
-                bv[u] = (o < a.HWo && co_ok) ? ldg1(Gn + (size_t)o * a.Cout) : 0.f;
+    constexpr int NA = 8, NG = 8;   // float4 slots per work-item: 255 rows x 8 / 256, 128 rows x 16 / 256
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kq = lane >> 4;
+    const int S = a.S, RI = S * a.HWv, RO = S * a.HWo, RO4 = (RO + 3) & ~3;
+    float* Al = reinterpret_cast<float*>(rdmi_lds);            // [RI + 1][WG_AS]; row RI = zeros
+    float* Gl = Al + (RI + 1) * WG_AS;                         // [RO4][WG_GS]
+    uint32_t* rt = reinterpret_cast<uint32_t*>(Gl + RO4 * WG_GS);   // [RO4][4]: byte t = staged ACT row of (row, tap t)
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 64;
+    for (int e = tid; e < RO4 * 4; e += RDMI_THREADS) {
+        const int row = e >> 2, w = e & 3;
+        uint32_t v = 0;
+        for (int bb = 0; bb < 4; ++bb) {
+            const int t = 4 * w + bb;
+            int idx = RI;
+            if (t < NTAP && row < RO) {
+                const int sidx = row / a.HWo, o = row - sidx * a.HWo;
+                const int pix = a.tab ? a.tab[o * NTAP + t] : o;
+                if (pix >= 0) idx = sidx * a.HWv + pix;
             }
+            v |= (uint32_t)idx << (8 * bb);
+        }
+        rt[e] = v;
+    }
+    if (tid < WG_AS) Al[RI * WG_AS + tid] = 0.f;
+    const int chunks = (a.NB + S - 1) / S, cper = (chunks + a.ksplit - 1) / a.ksplit;
+    const int n_lo = blockIdx.x * cper * S, n_hi = min(a.NB, n_lo + cper * S);
+    const bool gvec = (a.Cout & 3) == 0;
+    f32x4 ra[NA], rg[NG];
+    auto fetch = [&](int n0) {
+        const int nv = min(S, n_hi - n0);
+        const int rows_a = nv * a.HWv, rows_g = nv * a.HWo;
+        const float* Ab = a.ACT + (size_t)n0 * a.HWv * a.lda;
+        const float* Gb = a.G + (size_t)n0 * a.HWo * a.Cout;
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc = mfma16(av[u], bv[u], acc);
+        for (int i = 0; i < NA; ++i) {
+            const int e = i * RDMI_THREADS + tid, row = e >> 3, c = ci0 + 4 * (e & 7);
+            ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < rows_a && c + 3 < a.lda) ra[i] = ldg4(Ab + (size_t)row * a.lda + c);
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = i * RDMI_THREADS + tid, row = e >> 4, c = co0 + 4 * (e & 15);
+            rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < rows_g) {
+                const float* g = Gb + (size_t)row * a.Cout + c;
+                if (gvec) { if (c + 3 < a.Cout) rg[i] = ldg4(g); }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (c + q < a.Cout) rg[i][q] = ldg1(g + q);
+                }
+            }
+        }
+    };
+    f32x4 acc[NTAP][2];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+    if (n_lo < n_hi) fetch(n_lo);
+    const int acol = (wave & 1) * 16 + lrow, gcol = (wave >> 1) * 32 + lrow;
+    for (int n0 = n_lo; n0 < n_hi; n0 += S) {
+        __syncthreads();                                        // previous chunk fully consumed (and table / zero row written)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = i * RDMI_THREADS + tid, row = e >> 3;
+            if (row < RI) *reinterpret_cast<f32x4*>(Al + row * WG_AS + 4 * (e & 7)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int e = i * RDMI_THREADS + tid, row = e >> 4;
+            if (row < RO4) *reinterpret_cast<f32x4*>(Gl + row * WG_GS + 4 * (e & 15)) = rg[i];
+        }
+        __syncthreads();
+        if (n0 + S < n_hi) fetch(n0 + S);
+        for (int ks = 0; ks < RO4; ks += 4) {
+            const int row = ks + kq;
+            const float b0 = Gl[row * WG_GS + gcol], b1 = Gl[row * WG_GS + gcol + 16];
+            if (NTAP == 1) {
+                const float av = Al[min(row, RI) * WG_AS + acol];
+                acc[0][0] = mfma16(av, b0, acc[0][0]); acc[0][1] = mfma16(av, b1, acc[0][1]);
+            } else {
+                const uint32_t w0 = rt[row * 4], w1 = rt[row * 4 + 1], w2 = rt[row * 4 + 2];
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    const uint32_t w = t < 4 ? w0 : t < 8 ? w1 : w2;
+                    const int idx = (int)((w >> (8 * (t & 3))) & 255u);
+                    const float av = Al[idx * WG_AS + acol];
+                    acc[t][0] = mfma16(av, b0, acc[t][0]); acc[t][1] = mfma16(av, b1, acc[t][1]);
+                }
+            }
         }
     }
-    // D[row = ci_local][col = co_local]: lane holds col = lrow, rows kq*4 + r
-    for (int r = 0; r < 4; ++r) {
-        const int ci_out = blockIdx.y * 32 + (wave & 1) * 16 + kq * 4 + r;
-        if (ci_out < a.Cin && co_ok) atomicAdd(a.dW + co * a.s_co + ci_out * a.s_ci + tap * a.s_t, acc[r]);
+    // D[row = ci_local][col = co_local]: lane holds col = lrow, rows kq*4 + r.
+    if (NTAP == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + (wave & 1) * 16 + kq * 4 + r, co = co0 + (wave >> 1) * 32 + j * 16 + lrow;
+                if (ci < a.Cin && co < a.Cout) atomicAdd(a.dW + co * a.s_co + ci * a.s_ci, acc[0][j][r]);
+            }
+    } else {
+        // transpose through LDS to the OIHW order ([co][ci][tap] is contiguous per co) so that one atomic instruction
+        // covers 64 consecutive floats instead of 64 different cache lines
+        constexpr int RS = 32 * NTAP + 1;
+        float* stg = reinterpret_cast<float*>(rdmi_lds);       // [64][RS]
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stg[((wave >> 1) * 32 + j * 16 + lrow) * RS + ((wave & 1) * 16 + kq * 4 + r) * NTAP + t] = acc[t][j][r];
+        __syncthreads();
+        for (int e = tid; e < 64 * 32 * NTAP; e += RDMI_THREADS) {
+            const int col = e / (32 * NTAP), rem = e - col * (32 * NTAP), cil = rem / NTAP, t = rem - cil * NTAP;
+            const int ci = ci0 + cil, co = co0 + col;
+            if (ci < a.Cin && co < a.Cout) atomicAdd(a.dW + co * a.s_co + ci * a.s_ci + t * a.s_t, stg[col * RS + rem]);
+        }
     }
 }
 

@@ -48,6 +48,21 @@ namespace {
 
 std::map<rdmi_ctx*, TrainPlan*>& train_registry() { static std::map<rdmi_ctx*, TrainPlan*> r; return r; }
 
+// split the batch so that ~1000 workgroups exist whatever the layer's channel counts
+int launch_wgrad(WgradArgs w, hipStream_t s) {
+    if (w.lda & 3) return fail("wgrad: ACT row stride %d is not a multiple of 4", w.lda);
+    if (w.HWv > 255 || w.HWo > 128) return fail("wgrad: image of %d -> %d pixels does not fit the staged chunk", w.HWv, w.HWo);
+    w.S = wgrad_chunk(w.HWv, w.HWo);
+    const int tiles = ceil_div(w.Cin, 32) * ceil_div(w.Cout, 64), chunks = ceil_div(w.NB, w.S);
+    w.ksplit = std::max(1, std::min(chunks, 512 / tiles));
+    const dim3 grid((unsigned)w.ksplit, (unsigned)ceil_div(w.Cin, 32), (unsigned)ceil_div(w.Cout, 64));
+    const size_t lds = wgrad_lds_bytes(w.HWv, w.HWo, w.S);
+    if (w.ntap == 9) hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(RDMI_THREADS), lds, s, w);
+    else if (w.ntap == 1) hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(RDMI_THREADS), lds, s, w);
+    else return fail("wgrad: %d taps", w.ntap);
+    return 0;
+}
+
 int launch_small_gemm(const SgemmArgs& g, hipStream_t s) {
     // weight-gradient shapes contract over the batch: split K so that ~1024 workgroups are in flight
     const int tiles = ceil_div(g.M, 64) * ceil_div(g.N, 64);
@@ -287,6 +302,8 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
     static bool attr = false;
     if (!attr) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
@@ -347,12 +364,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
             w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
             w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
-            {   // split the batch so that ~1000 workgroups exist whatever the layer's channel counts
-                const int tiles = 9 * ceil_div(Cin, 32) * ceil_div(sp.Cout, 32);
-                w.ksplit = std::max(1, std::min(NB, 1024 / tiles));
-                hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)(9 * w.ksplit), (unsigned)ceil_div(Cin, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS),
-                                   (size_t)(fa.HWo + 4) * 4, s, w);
-            }
+            if (int e = launch_wgrad(w, s)) return e;
         }
         // scatter the input gradient to the source tensors
         if (b.has_dgrad) {
@@ -376,12 +388,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
             w.NB = NB; w.HWv = fa.HWo; w.HWo = fa.HWo; w.Cin = Csc; w.Cout = sp.Cout; w.ntap = 1; w.lda = fa.Csc;
             w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
-            {
-                const int tiles = ceil_div(Csc, 32) * ceil_div(sp.Cout, 32);
-                w.ksplit = std::max(1, std::min(NB, 1024 / tiles));
-                hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)w.ksplit, (unsigned)ceil_div(Csc, 32), (unsigned)ceil_div(sp.Cout, 32)), dim3(RDMI_THREADS),
-                                   (size_t)(fa.HWo + 4) * 4, s, w);
-            }
+            if (int e = launch_wgrad(w, s)) return e;
             const long tot = (long)NB * fa.HWsa * fa.CscA + (long)NB * fa.HWo * fa.CscB;
             hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GS,
                                gptr(op.tScA), gptr(op.tScB), b.has_invS ? T.d_int + b.invS_start : (const int*)nullptr,
