@@ -9,7 +9,8 @@ from rdmi import sde_lib
 from rdmi.models import utils as mutils
 dev = torch.device('cuda:0')
 model, cfg, _ = ge.make_model(dev)
-B = 128
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+QUIET = len(sys.argv) > 2
 sde = sde_lib.RVESDE(0.01, 5, N=1000)
 x = torch.rand(B, 1, 9, 9, device=dev); t = torch.full((B,), 0.5, device=dev); lab = torch.rand(B, 1, device=dev)
 fn = mutils.get_cf_score_fn(sde, model, lab, 0.0)
@@ -23,7 +24,7 @@ ops = ctx.op_cycles()
 tot = sum(c for _, c in ops)
 agg = {}
 for i, (d, c) in enumerate(ops):
-    print(f'{i:3d} {c:8d} {100*c/tot:5.1f}%  {d}' + (f'   fine(entry,ring,kind,prefetch,main,epi)={ctx.fine[i]}' if d.startswith('CONV') and i < len(ctx.fine) else ''))
+    if not QUIET: print(f'{i:3d} {c:8d} {100*c/tot:5.1f}%  {d}' + (f'   fine(entry,ring,kind,prefetch,main,epi)={ctx.fine[i]}' if d.startswith('CONV') and i < len(ctx.fine) else ''))
     k = d.split()[0] + (' ' + d.split()[1] if d.startswith('CONV') else '')
     agg[k] = agg.get(k, 0) + c
 print('total cycles', tot, ' (100 MHz ticks?)')
