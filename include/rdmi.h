@@ -107,6 +107,18 @@ int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch,
                  float* dscore /* NULL or [B,E]: d per_sample / d score for the backward */, int B, int elems_per_sample,
                  double sigma_min, double sigma_max, int likelihood_weighting, int reduce_mean, void* stream);
 
+/* Post-sampling un-normalisation of the GTO-Halo samples (Benchmark/gto_halo_benchmarking.py:255-333, :335-361):
+ * samples [N, row_elems] (the flattened [N,1,9,9] sampler output, row_elems >= 67) -> out [N, 67] physical vectors
+ * (halo energy, shooting/coast times, 20 x (alpha, theta, |u| clipped to 1), fuel mass, halo period, manifold length);
+ * *clip_count (device, may be NULL; caller zeroes it) += number of control magnitudes that exceeded 1. */
+int rdmi_gto_unnormalize(const float* samples, float* out, unsigned long long* clip_count, int N, int row_elems, void* stream);
+
+/* Training-data side (RD/datasets.py:82-98 GTOHaloImageDataset.__getitem__): gather rows idx[0..B) (NULL: rows
+ * 0..B-1) of a device-resident table data[rows][row_len] into images [B, elems] = (zero-pad(vec, elems) - mean) / std and
+ * labels [B] = vec[0] (un-normalised), replacing the per-item np.pad loader.  Indices are the caller's to keep in range. */
+int rdmi_gto_pack(const float* data, const long long* idx, float* images, float* labels, int B, int row_len, int elems,
+                  double mean, double std, void* stream);
+
 /* Training step (RD/losses.py:141-149): train-mode forward of NCSNpp (Dropout_0 with probability dropout_p on the input of
  * every Conv_1, RD/models/layerspp.py:204; label drop is the caller's, RD/models/ncsnpp.py:242-246) keeping every
  * activation, and the backward pass.  rdmi_enable_training switches the context to the layer plan with per-tensor storage

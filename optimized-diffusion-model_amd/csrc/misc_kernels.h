@@ -420,3 +420,53 @@ __global__ __launch_bounds__(RDMI_THREADS) void nhwc_to_nchw_kernel(const float*
     const long n = r / HW;
     dst[(n * C + c) * HW + p] = src[i];
 }
+
+// Post-sampling un-normalisation of the GTO-Halo 67-vectors (Benchmark/gto_halo_benchmarking.py:255-333 and
+// _convert_to_spherical :335-361): first 67 of the 81 image values; column 0 = halo energy, 1..66 = model outputs
+// m*0.1811+0.4652, then per-variable ranges; the 20 control triplets (ux,uy,uz)*2-1 -> (alpha, theta, min(|u|,1)).
+// One work-item per (sample, unit): units 0..19 = control triplets, 20 = head columns 0..3, 21 = tail columns 64..66.
+__global__ __launch_bounds__(RDMI_THREADS) void gto_unnormalize_kernel(const float* __restrict__ samples, float* __restrict__ out,
+                                                                        unsigned long long* __restrict__ clips, int N, int E) {
+    const int i = blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= N * 22) return;
+    const int n = i / 22, unit = i - n * 22;
+    const float* s = samples + (size_t)n * E;
+    float* o = out + (size_t)n * 67;
+    const float mean = 0.4652f, sd = 0.1811f, two_pi = 6.283185307179586f;
+    auto m = [&](int j) { return s[1 + j] * sd + mean; };        // model_outputs[:, j]
+    if (unit == 20) {
+        o[0] = s[0] * (float)(0.095 - 0.008) + 0.008f;                 // halo energy from the normalised class label
+        o[1] = m(0) * 40.0f + 0.0f;
+        o[2] = m(1) * 15.0f + 0.0f;
+        o[3] = m(2) * 15.0f + 0.0f;
+    } else if (unit == 21) {
+        o[64] = m(63) * 62.0f + 408.0f;                           // final fuel mass
+        o[65] = m(64);                                            // halo period stays normalised (:322)
+        o[66] = m(65) * 6.0f + 5.0f;                              // manifold length
+    } else {
+        const int j = 3 + 3 * unit;
+        const float ux = m(j) * 2.0f * 1.0f - 1.0f, uy = m(j + 1) * 2.0f * 1.0f - 1.0f, uz = m(j + 2) * 2.0f * 1.0f - 1.0f;
+        float u = sqrtf(ux * ux + uy * uy + uz * uz);
+        float theta = u != 0.f ? asinf(uz / u) : 0.f;
+        float alpha = atan2f(uy, ux);
+        alpha = alpha >= 0.f ? alpha : two_pi + alpha;
+        theta = theta >= 0.f ? theta : two_pi + theta;
+        if (u > 1.f) { u = 1.f; if (clips) atomicAdd(clips, 1ull); }
+        o[1 + j] = alpha; o[2 + j] = theta; o[3 + j] = u;
+    }
+}
+
+// Training-data side (RD/datasets.py:82-98, GTOHaloImageDataset.__getitem__): row idx[b] of the device-resident table
+// [rows][L] -> image[b] = (pad(vec, E) - mean) / std  (the zero padding is normalised too) and label[b] = vec[0].
+__global__ __launch_bounds__(RDMI_THREADS) void gto_pack_kernel(const float* __restrict__ data, const long long* __restrict__ idx,
+                                                                 float* __restrict__ images, float* __restrict__ labels, int B, int L, int E,
+                                                                 float mean, float sd) {
+    const int i = blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= B * E) return;
+    const int b = i / E, e = i - b * E;
+    const float* row = data + (size_t)(idx ? idx[b] : b) * L;
+    const float v = e < L ? row[e] : 0.f;
+    images[i] = (v - mean) / sd;
+    if (e == 0) labels[b] = v;
+}
+

@@ -1430,6 +1430,27 @@ int rdmi_perturb(const float* batch, const float* z, const float* t, float* out,
     return 0;
 }
 
+int rdmi_gto_pack(const float* data, const long long* idx, float* images, float* labels, int B, int row_len, int elems, double mean,
+                  double std, void* stream) {
+    if (B == 0) return 0;
+    if (!data || !images || !labels) return fail("null argument");
+    if (B < 0 || row_len < 1 || elems < row_len) return fail("gto_pack: rows of %d values into images of %d", row_len, elems);
+    hipLaunchKernelGGL(gto_pack_kernel, dim3((unsigned)ceil_div(B * elems, RDMI_THREADS)), dim3(RDMI_THREADS), 0, (hipStream_t)stream, data, idx, images,
+                       labels, B, row_len, elems, (float)mean, (float)std);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int rdmi_gto_unnormalize(const float* samples, float* out, unsigned long long* clip_count, int N, int row_elems, void* stream) {
+    if (N == 0) return 0;
+    if (!samples || !out) return fail("null argument");
+    if (N < 0 || row_elems < 67) return fail("gto_unnormalize: rows of %d values (need >= 67)", row_elems);
+    hipLaunchKernelGGL(gto_unnormalize_kernel, dim3((unsigned)ceil_div(N * 22, RDMI_THREADS)), dim3(RDMI_THREADS), 0, (hipStream_t)stream, samples, out,
+                       clip_count, N, row_elems);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int rdmi_sm_loss(const float* score, const float* perturbed, const float* batch, const float* t, float* per_sample,
                  float* dscore, int B, int E, double sigma_min, double sigma_max, int likelihood_weighting, int reduce_mean,
                  void* stream) {

@@ -46,6 +46,8 @@ _PROTOS = {
     'rdmi_reflect': ([_F, _F, C.c_size_t, C.c_void_p], C.c_int),
     'rdmi_score_hk': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_perturb': ([_F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
+    'rdmi_gto_pack': ([_F, C.c_void_p, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
+    'rdmi_gto_unnormalize': ([_F, _F, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
     'rdmi_sm_loss': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p], C.c_int),
     'rdmi_enable_training': ([C.c_void_p], C.c_int),
     'rdmi_train_forward': ([C.c_void_p, _F, _F, _F, _F, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
@@ -261,6 +263,35 @@ def perturb(batch, z, t, smin, smax):
     check(lib().rdmi_perturb(ptr(batch.contiguous()), ptr(z.contiguous()), ptr(t.contiguous().float()), ptr(out), B,
                              batch.numel() // B, smin, smax, stream_of(batch)))
     return out
+
+
+def gto_pack(data, idx, elems, mean, std):
+    """data [rows, L] fp32 device table, idx [B] int64 (or None) -> (images [B, elems], labels [B]); RD/datasets.py:82-98."""
+    require_device(data)
+    assert data.dim() == 2 and data.dtype == torch.float32 and data.is_contiguous()
+    B = data.shape[0] if idx is None else idx.numel()
+    if idx is not None:
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.device == data.device
+    images = torch.empty(B, elems, dtype=torch.float32, device=data.device)
+    labels = torch.empty(B, dtype=torch.float32, device=data.device)
+    check(lib().rdmi_gto_pack(ptr(data), None if idx is None else idx.data_ptr(), ptr(images), ptr(labels), B, data.shape[1],
+                              elems, mean, std, stream_of(data)))
+    return images, labels
+
+
+def gto_unnormalize(samples):
+    """samples [N, ...>=67 values per sample] on the device -> (out [N, 67] physical vectors, clip count tensor [1] int64);
+    Benchmark/gto_halo_benchmarking.py:255-361."""
+    require_device(samples)
+    N = samples.shape[0]
+    row = 1
+    for d in samples.shape[1:]:
+        row *= int(d)
+    flat = samples.reshape(N, row).contiguous().float()
+    out = torch.empty(N, 67, dtype=torch.float32, device=samples.device)
+    clips = torch.zeros(1, dtype=torch.int64, device=samples.device)
+    check(lib().rdmi_gto_unnormalize(ptr(flat), ptr(out), clips.data_ptr(), N, flat.shape[1], stream_of(samples)))
+    return out, clips
 
 
 def sm_loss(score, perturbed, batch, t, smin, smax, likelihood_weighting, reduce_mean, want_grad=False):

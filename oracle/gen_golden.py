@@ -253,8 +253,55 @@ def gen_init():
              'down_attn.1.NIN_3.W', 'up_blocks.6.Dense_0.weight', 'upsample.1.Conv_0.weight', 'out_conv.weight']})
 
 
+def gen_gto():
+    """SURVEY 8f N1.  Benchmark/gto_halo_benchmarking.py cannot be imported (omegaconf is absent), and the un-normalisation is
+    inline in generate_samples, so only its helper method _convert_to_spherical (:335-361) is run: the method's AST node is
+    compiled from the reference file in memory (nothing is copied) and called with a stub `self` holding the two counters."""
+    import ast
+    path = '/root/reference/Benchmark/gto_halo_benchmarking.py'
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == '_convert_to_spherical')
+    ns = {'np': np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, 'exec'), ns)
+    rng = np.random.RandomState(7)
+    u3 = (rng.rand(64, 20, 3).astype(np.float32) * 2.6 - 1.3)
+    u3[0, 0] = 0.0                                   # |u| = 0 branch
+    u3[0, 1] = [1.0, 0.0, 0.0]; u3[0, 2] = [-1.0, 0.0, 0.0]; u3[0, 3] = [0.0, -1.0, 0.0]; u3[0, 4] = [0.0, 0.0, -1.0]
+    u3[0, 5] = [0.6, -0.8, 0.0]; u3[0, 6] = [2.0, 2.0, 2.0]
+    stub = NS(total_spherical_clips=0, total_spherical_elements=0)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        a, th, u = ns['_convert_to_spherical'](stub, u3[..., 0].copy(), u3[..., 1].copy(), u3[..., 2].copy())
+    save('gto_unnormalize.npz', ux=u3[..., 0], uy=u3[..., 1], uz=u3[..., 2], alpha=a, theta=th, u=u,
+         clips=np.int64(stub.total_spherical_clips))
+
+
+def gen_gto_dataset():
+    """SURVEY 8f N3.  RD/datasets.py imports torchvision (absent), so only the class GTOHaloImageDataset (:82-98) is compiled
+    from the file's AST in memory; its __init__ (a pickle.load of a data file that is not here) is bypassed by setting the
+    three attributes it would set."""
+    import ast
+    path = REF + '/datasets.py'
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == 'GTOHaloImageDataset')
+    ns = {'np': np, 'torch': torch, 'Dataset': object}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), path, 'exec'), ns)
+    ds = object.__new__(ns['GTOHaloImageDataset'])
+    rng = np.random.RandomState(11)
+    ds.data = rng.rand(37, 67).astype(np.float32)
+    ds.mean, ds.std = 0.4652, 0.1811
+    items = [ds[i] for i in range(len(ds))]
+    save('gto_dataset.npz', data=ds.data, images=np.stack([im.numpy() for im, _ in items]), labels=np.stack([lb.numpy() for _, lb in items]))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['gto']:
+        gen_gto()
+        gen_gto_dataset()
+        sys.exit(0)
+    gen_gto_dataset()
+    gen_gto()
     gen_cube_sde()
     gen_forward()
     gen_sampler()

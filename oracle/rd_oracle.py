@@ -398,3 +398,51 @@ def sde_loss(p, sde, batch, labels, t, z, arch=DEFAULT_ARCH, drop_masks=None, dr
     losses = (std ** 2)[:, None, None, None] * (score - target) ** 2
     per = F32(0.5) * losses.reshape(losses.shape[0], -1).sum(-1, dtype=F32)
     return per.mean(dtype=F32), score, target, perturbed
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# post-sampling un-normalisation (Benchmark/gto_halo_benchmarking.py:255-333, :335-361).
+# The Benchmark module itself is not importable here (omegaconf absent); the spherical conversion is pinned by vectors
+# recorded from the reference's own _convert_to_spherical (tests/golden/gto_unnormalize.npz, made by oracle/gen_golden.py);
+# the affine part around it is a restatement checked by hand-computed known answers only ("parity unpinned" for it).
+def convert_to_spherical(ux, uy, uz):
+    """:335-361 -> (alpha, theta, u, number of clipped magnitudes)."""
+    ux, uy, uz = (np.asarray(a, np.float32) for a in (ux, uy, uz))
+    u = np.sqrt(ux ** 2 + uy ** 2 + uz ** 2)
+    theta = np.zeros_like(u)
+    nz = u != 0
+    theta[nz] = np.arcsin(uz[nz] / u[nz])
+    alpha = np.arctan2(uy, ux)
+    alpha = np.where(alpha >= 0, alpha, 2 * np.pi + alpha)
+    theta = np.where(theta >= 0, theta, 2 * np.pi + theta)
+    clips = int(np.sum(u > 1))
+    u = np.where(u > 1, np.float32(1), u)
+    return alpha.astype(np.float32), theta.astype(np.float32), u.astype(np.float32), clips
+
+
+def gto_unnormalize(samples):
+    """samples [N, >=67] float32 -> ([N, 67] float32, clips)  (:255-333)."""
+    s = np.asarray(samples, np.float32).reshape(len(samples), -1)[:, :67]
+    lab = s[:, 0]
+    m = s[:, 1:] * np.float32(0.1811) + np.float32(0.4652)
+    m[:, 0] = m[:, 0] * (40 - 0) + 0
+    m[:, 1] = m[:, 1] * (15 - 0) + 0
+    m[:, 2] = m[:, 2] * (15 - 0) + 0
+    m[:, 3:-3] = m[:, 3:-3] * 2 * 1.0 - 1.0
+    ctrl = m[:, 3:-3].reshape(len(s), -1, 3)
+    a, th, u, clips = convert_to_spherical(ctrl[:, :, 0], ctrl[:, :, 1], ctrl[:, :, 2])
+    ctrl = np.stack([a, th, u], axis=-1)
+    m[:, 3:-3] = ctrl.reshape(len(s), -1)
+    m[:, -3] = m[:, -3] * (470 - 408) + 408
+    m[:, -1] = m[:, -1] * (11 - 5) + 5
+    halo = lab * np.float32(0.095 - 0.008) + np.float32(0.008)
+    return np.column_stack((halo, m)).astype(np.float32), clips
+
+
+# SURVEY 8f N3: GTOHaloImageDataset.__getitem__ (RD/datasets.py:88-98), pinned by items recorded from the reference class.
+def gto_image_item(vec, elems=81, mean=0.4652, std=0.1811):
+    vec = np.asarray(vec, np.float32)
+    padded = np.pad(vec, (0, elems - len(vec)), 'constant')
+    padded = (padded - mean) / std
+    return padded.astype(np.float32), np.array([vec[0]], np.float32)
+

@@ -91,6 +91,7 @@ inline float atomicAdd(float* p, float v) {   // workgroups run on parallel OS t
     std::memcpy(&f, &old, 4);
     return f;
 }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
 template <class T, class U> inline T __builtin_bit_cast_emu(U u) { T t; std::memcpy(&t, &u, sizeof(T)); return t; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values

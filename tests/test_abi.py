@@ -24,7 +24,7 @@ def declared_symbols():
 def test_header_declares_the_documented_surface():
     syms = declared_symbols()
     for must in ('rdmi_create', 'rdmi_destroy', 'rdmi_set_param', 'rdmi_forward', 'rdmi_score', 'rdmi_cf_score',
-                 'rdmi_pc_sample', 'rdmi_reflect', 'rdmi_score_hk', 'rdmi_em_update', 'rdmi_langevin_update', 'rdmi_perturb', 'rdmi_sm_loss', 'rdmi_enable_training', 'rdmi_train_forward', 'rdmi_backward',
+                 'rdmi_pc_sample', 'rdmi_reflect', 'rdmi_score_hk', 'rdmi_em_update', 'rdmi_langevin_update', 'rdmi_perturb', 'rdmi_sm_loss', 'rdmi_gto_unnormalize', 'rdmi_gto_pack', 'rdmi_enable_training', 'rdmi_train_forward', 'rdmi_backward',
                  'rdmi_last_error'):
         assert must in syms
 

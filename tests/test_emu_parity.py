@@ -104,6 +104,44 @@ def test_cube_helpers(emu, golden):
     assert bool(cube.inside(torch.rand(3, 1, 9, 9)).all())
 
 
+def test_gto_dataset_batches(emu, golden):
+    """device-resident table -> batches, bit-exact against items recorded from the reference dataset class."""
+    from rdmi import datasets
+    g = golden('gto_dataset.npz')
+    ds = datasets.GTOHaloImageDataset(g['data'], 'cpu')
+    assert len(ds) == 37
+    img, lab = ds.batch(None)
+    assert np.array_equal(img.numpy(), g['images']) and np.array_equal(lab.numpy(), g['labels'])
+    idx = torch.tensor([36, 0, 5, 5, 17], dtype=torch.int64)
+    img, lab = ds.batch(idx)
+    assert np.array_equal(img.numpy(), g['images'][idx.numpy()]) and np.array_equal(lab.numpy(), g['labels'][idx.numpy()])
+    im0, lb0 = ds[3]
+    assert im0.shape == (1, 9, 9) and np.array_equal(im0.numpy(), g['images'][3]) and np.array_equal(lb0.numpy(), g['labels'][3])
+    seen = torch.cat([lab for _, lab in ds.epoch(6, generator=torch.Generator().manual_seed(0), drop_last=False)])
+    assert sorted(seen.view(-1).tolist()) == sorted(g['labels'].reshape(-1).tolist())          # one epoch = every item once
+    with pytest.raises(ValueError):
+        datasets.GTOHaloImageDataset(np.zeros((2, 82), np.float32), 'cpu')
+
+
+def test_gto_unnormalize(emu, golden):
+    """HIP un-normalisation kernel vs the oracle (spherical part pinned by reference-recorded vectors).
+    Tolerance: angles from asinf/atan2f of this libm vs numpy's, 2e-6 rad; affine parts 1e-6 relative (fma contraction)."""
+    from rdmi import harness
+    g = golden('gto_unnormalize.npz')
+    N = g['ux'].shape[0]
+    ctrl = np.stack([g['ux'], g['uy'], g['uz']], -1).reshape(N, 60)
+    s = np.random.RandomState(3).rand(N, 81).astype(np.float32) * 1.4 - 0.2
+    s[:, 4:64] = ((ctrl + 1) / 2 - 0.4652) / 0.1811                    # so that the kernel sees (about) the recorded triplets
+    out, clips = harness.unnormalize_gto(T(s).reshape(N, 1, 9, 9))
+    ref, rclips = O.gto_unnormalize(s)
+    big = np.abs(ref[:, 4:64].reshape(N, 20, 3)[..., :2] - out.numpy()[:, 4:64].reshape(N, 20, 3)[..., :2])
+    assert np.all(np.minimum(big, np.abs(big - 2 * np.pi)) < 5e-5)      # angles (a wrap at 0 / 2pi is the same direction)
+    np.testing.assert_allclose(out.numpy()[:, 6:64:3], ref[:, 6:64:3], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(out.numpy()[:, :4], ref[:, :4], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(out.numpy()[:, 64:], ref[:, 64:], rtol=2e-6, atol=1e-6)
+    assert abs(int(clips.item()) - rclips) <= 2                          # |u| within an ulp of 1 may flip
+
+
 @pytest.mark.parametrize('corr', ['none', 'langevin'])
 def test_fused_sampler_vs_oracle(env, corr):
     """3 reflected PC updates (N=4), B=2, CFG on, injected noise: the C loop (rdmi_pc_sample) against the oracle."""

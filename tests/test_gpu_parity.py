@@ -348,3 +348,57 @@ def test_dropout_and_label_drop_train_mode(env):
         p.add_(h * d)
     fd = (lp - lm) / (2 * h)
     assert abs(fd - gd) <= 0.05 * abs(gd) + 1e-3, (fd, gd)
+
+
+def test_gto_unnormalize(env, golden):
+    """SURVEY 8f N1 on the GPU: un-normalisation of sampler output to physical 67-vectors vs the oracle; spherical part against
+    vectors recorded from the reference helper.  Tolerances as in tests/test_emu_parity.py::test_gto_unnormalize."""
+    from oracle import rd_oracle as O
+    from rdmi import harness
+    dev = env['dev']
+    g = golden('gto_unnormalize.npz')
+    N = g['ux'].shape[0]
+    ctrl = np.stack([g['ux'], g['uy'], g['uz']], -1).reshape(N, 60)
+    s = np.random.RandomState(3).rand(N, 81).astype(np.float32) * 1.4 - 0.2
+    s[:, 4:64] = ((ctrl + 1) / 2 - 0.4652) / 0.1811
+    out, clips = harness.unnormalize_gto(T(s, dev).reshape(N, 1, 9, 9))
+    out = out.cpu().numpy()
+    ref, rclips = O.gto_unnormalize(s)
+    d = np.abs(ref[:, 4:64].reshape(N, 20, 3)[..., :2] - out[:, 4:64].reshape(N, 20, 3)[..., :2])
+    assert np.all(np.minimum(d, np.abs(d - 2 * np.pi)) < 5e-5)
+    np.testing.assert_allclose(out[:, 6:64:3], ref[:, 6:64:3], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(out[:, :4], ref[:, :4], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(out[:, 64:], ref[:, 64:], rtol=2e-6, atol=1e-6)
+    assert abs(int(clips.item()) - rclips) <= 2
+    # full size: 100k samples, every magnitude <= 1, angles in [0, 2pi), ragged N, empty input
+    big = torch.rand(100003, 1, 9, 9, device=dev)
+    o2, c2 = harness.unnormalize_gto(big)
+    sph = o2[:, 4:64].reshape(-1, 20, 3)
+    assert float(sph[..., 2].max()) <= 1.0 and float(sph[..., :2].min()) >= 0.0 and float(sph[..., :2].max()) < 6.2832
+    o0, _ = harness.unnormalize_gto(torch.zeros(0, 1, 9, 9, device=dev))
+    assert o0.shape == (0, 67)
+
+
+def test_gto_dataset_batches(env, golden):
+    """SURVEY 8f N3 on the GPU: gather + pad + normalise + label in one kernel, bit-exact against items recorded from the
+    reference's GTOHaloImageDataset; sharded epochs partition the table; a 300k-row table runs at full size."""
+    from rdmi import datasets
+    dev = env['dev']
+    g = golden('gto_dataset.npz')
+    ds = datasets.GTOHaloImageDataset(g['data'], dev)
+    img, lab = ds.batch(None)
+    assert np.array_equal(img.cpu().numpy(), g['images']) and np.array_equal(lab.cpu().numpy(), g['labels'])
+    idx = torch.tensor([36, 0, 5, 5, 17], dtype=torch.int64, device=dev)
+    img, lab = ds.batch(idx)
+    assert np.array_equal(img.cpu().numpy(), g['images'][idx.cpu().numpy()])
+    parts = [torch.cat([lab for _, lab in ds.epoch(4, generator=torch.Generator(device=dev).manual_seed(5), drop_last=False, rank=r, world_size=2)])
+             for r in range(2)]
+    assert sorted(torch.cat(parts).view(-1).tolist()) == sorted(g['labels'].reshape(-1).tolist())
+    big = np.random.RandomState(0).rand(300000, 67).astype(np.float32)
+    dsb = datasets.GTOHaloImageDataset(big, dev)
+    img, lab = dsb.sample_batch(4096, generator=torch.Generator(device=dev).manual_seed(1))
+    assert img.shape == (4096, 1, 9, 9) and lab.shape == (4096, 1)
+    flat = img.view(4096, 81)
+    assert torch.equal(flat[:, 0] * 0.1811 + 0.4652 - lab[:, 0] < 1e-6, torch.ones(4096, dtype=torch.bool, device=dev))
+    assert torch.all(flat[:, 67:] == torch.tensor((0.0 - 0.4652) / 0.1811, dtype=torch.float32, device=dev))
+

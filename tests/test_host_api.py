@@ -131,3 +131,59 @@ def test_flatten_helpers_and_sigmas():
     assert mutils.from_flattened_numpy(mutils.to_flattened_numpy(x), (3, 4)).equal(x)
     s = mutils.get_sigmas(NS(sde=NS(sigma_max=5, sigma_min=0.01, num_scales=7)))
     assert s.shape == (7,) and np.isclose(s[0], 5) and np.isclose(s[-1], 0.01)
+
+
+class _NotPlain:                                        # stands for the omegaconf object the reference pickles
+    pass
+
+
+def test_checkpoint_layout_round_trip(tmp_path, golden):
+    """the reference's checkpoint layout (RD/utils.py:48-86; EMA list layout RD/models/ema.py:92-99) written and
+    read back with the safe loader only; a reference-style file that carries a non-plain `config` object is refused loudly."""
+    import __graft_entry__ as ge
+    from rdmi import losses, utils
+    from rdmi.models import utils as mutils
+    from rdmi.models.ema import ExponentialMovingAverage
+    cfg = ge.demo_config()
+    torch.manual_seed(0)
+    model = mutils.create_model(cfg)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    for p in model.parameters():                       # one fake optimisation step so optimizer/EMA state is non-trivial
+        if p.requires_grad:
+            p.grad = torch.full_like(p, 1e-3)
+    opt.step(); ema.update(model.parameters())
+    state = dict(optimizer=opt, model=model, ema=ema, step=7, scaler=None, config=cfg)
+    path = str(tmp_path / 'checkpoint_1.pth')
+    utils.save_checkpoint(path, state)
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {'step', 'model', 'optimizer', 'ema', 'scaler', 'config'}
+    assert list(raw['model'].keys()) == list(golden('init_seed0.npz')['names'])       # the reference's own state_dict names
+    assert set(raw['ema']) == {'decay', 'num_updates', 'shadow_params'} and len(raw['ema']['shadow_params']) == 260
+    assert raw['config']['model']['nf'] == cfg.model.nf
+
+    torch.manual_seed(1)
+    model2 = mutils.create_model(cfg)
+    opt2 = losses.get_optimizer(cfg, model2.parameters())
+    ema2 = ExponentialMovingAverage(model2.parameters(), decay=cfg.model.ema_rate)
+    ptrs = [p.data_ptr() for p in model2.parameters()]
+    st2 = utils.restore_checkpoint(path, dict(optimizer=opt2, model=model2, ema=ema2, step=0, scaler=None), 'cpu')
+    assert st2['step'] == 7 and ema2.num_updates == ema.num_updates
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(ema.shadow_params, ema2.shadow_params))
+    assert [p.data_ptr() for p in model2.parameters()] == ptrs        # loaded in place: borrowed device pointers stay valid
+    s1, s2 = opt.state_dict()['state'], opt2.state_dict()['state']
+    assert all(torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) for k in s1)
+
+    model3 = utils.load_denoising_model(path, mutils.create_model(cfg))
+    assert torch.equal(model3.state_dict()['out_conv.weight'], model.state_dict()['out_conv.weight'])
+    with pytest.raises(ValueError, match='No checkpoint'):
+        utils.load_denoising_model(str(tmp_path / 'missing.pth'), model3)
+    # untouched state + directory creation when the file is absent (RD/utils.py:49-53)
+    st = dict(optimizer=opt, model=model, ema=ema, step=3, scaler=None)
+    assert utils.restore_checkpoint(str(tmp_path / 'new' / 'checkpoint.pth'), st, 'cpu') is st and (tmp_path / 'new').is_dir()
+
+    torch.save({'model': model.state_dict(), 'config': _NotPlain()}, str(tmp_path / 'ref_style.pth'))
+    with pytest.raises(RuntimeError, match='weights_only'):
+        utils.load_denoising_model(str(tmp_path / 'ref_style.pth'), model3)
+

@@ -119,3 +119,36 @@ def test_torch_flavour_oracle(golden, params0):
                               z_corr=torch.from_numpy(nz[2 * i]))
             close(xn.numpy(), steps[i], rtol=0, atol=2e-5 * amp[i])
             xcur = torch.from_numpy(steps[i])
+
+
+def test_gto_spherical_matches_reference_helper(golden):
+    """vectors recorded from the reference's own _convert_to_spherical (Benchmark/gto_halo_benchmarking.py:335-361),
+    including |u| = 0, axis-aligned directions (alpha / theta wrap to [0, 2pi)) and magnitudes > 1 (clipped, counted)."""
+    g = golden('gto_unnormalize.npz')
+    a, th, u, clips = O.convert_to_spherical(g['ux'], g['uy'], g['uz'])
+    assert np.array_equal(a, g['alpha']) and np.array_equal(th, g['theta']) and np.array_equal(u, g['u'])
+    assert clips == int(g['clips'])
+
+
+def test_gto_unnormalize_known_answers():
+    """The affine part of :255-333 has no importable reference (omegaconf) -> hand-computed known answers ("parity unpinned")."""
+    s = np.full((2, 81), 0.5, np.float32)
+    s[1, 0] = 1.0
+    out, clips = O.gto_unnormalize(s)
+    assert out.shape == (2, 67) and clips == 0
+    m = 0.5 * 0.1811 + 0.4652
+    np.testing.assert_allclose(out[0, 0], 0.5 * 0.087 + 0.008, rtol=1e-6)
+    np.testing.assert_allclose(out[1, 0], 0.095, rtol=1e-6)
+    np.testing.assert_allclose(out[0, 1:4], [m * 40, m * 15, m * 15], rtol=1e-6)
+    c = m * 2 - 1
+    np.testing.assert_allclose(out[0, 4:64].reshape(20, 3), np.tile([np.pi / 4, np.arcsin(1 / np.sqrt(3)), c * np.sqrt(3)], (20, 1)), rtol=2e-6)
+    np.testing.assert_allclose(out[0, 64:], [m * 62 + 408, m, m * 6 + 5], rtol=1e-6)
+
+
+def test_gto_dataset_item_matches_reference_class(golden):
+    """items recorded from the reference's GTOHaloImageDataset.__getitem__ (RD/datasets.py:88-98)."""
+    g = golden('gto_dataset.npz')
+    for i in range(len(g['data'])):
+        img, lab = O.gto_image_item(g['data'][i])
+        assert np.array_equal(img.reshape(1, 9, 9), g['images'][i]) and np.array_equal(lab, g['labels'][i])
+
