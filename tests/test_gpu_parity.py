@@ -350,6 +350,37 @@ def test_dropout_and_label_drop_train_mode(env):
     assert abs(fd - gd) <= 0.05 * abs(gd) + 1e-3, (fd, gd)
 
 
+@pytest.mark.parametrize('H,W,B,split', [(8, 9, 1000, 601), (9, 9, 4096, 2048)])
+def test_training_gradients_are_batch_additive(env, H, W, B, split):
+    """Full-size property of the backward pass (sizes the oracle cannot reach): with dropout off, the gradient of
+    sum_b <NCSNpp(x_b), r_b> over a batch equals the sum of the gradients over any split of that batch -- ragged split,
+    the [1,8,9] shape, and B=4096 (many chunks per workgroup in the weight-gradient and attention-backward kernels).
+    Tolerance: fp32 summation order differs between the runs (split-K atomics): 2e-4 of each tensor's max."""
+    from rdmi import autograd_fn
+    dev, ge = env['dev'], env['ge']
+    model, cfg, _ = ge.make_model(dev)
+    model.eval()                                       # dropout off; gradients still flow through autograd_fn
+    g = torch.Generator().manual_seed(H * 100 + B)
+    x = torch.rand(B, 1, H, W, generator=g).to(dev)
+    sig = (0.01 * 500 ** torch.rand(B, generator=g)).to(dev)
+    lab = torch.rand(B, 1, generator=g).to(dev)
+    r = torch.randn(B, 1, H, W, generator=g).to(dev)
+    names = ['input_conv.weight', 'down_blocks.1.Conv_0.weight', 'down_attn.0.NIN_1.W', 'down_attn.1.GroupNorm_0.weight', 'mid_block1.Dense_0.weight',
+             'time_mlp.0.weight', 'label_emb.weight', 'up_blocks.4.NIN_0.W', 'up_blocks.8.Conv_1.bias', 'upsample.0.Conv_0.weight', 'out_conv.weight']
+    params = dict(model.named_parameters())
+
+    def grads(sl):
+        model.zero_grad()
+        out = autograd_fn.ncsnpp_apply(model, x[sl], sig[sl], lab[sl])
+        (out * r[sl]).sum().backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        return {n: params[n].grad.detach().clone() for n in names}
+    full, a, b = grads(slice(0, B)), grads(slice(0, split)), grads(slice(split, B))
+    for n in names:
+        ref = a[n] + b[n]
+        assert torch.allclose(full[n], ref, rtol=0, atol=2e-4 * float(ref.abs().max()) + 1e-12), n
+
+
 def test_gto_unnormalize(env, golden):
     """SURVEY 8f N1 on the GPU: un-normalisation of sampler output to physical 67-vectors vs the oracle; spherical part against
     vectors recorded from the reference helper.  Tolerances as in tests/test_emu_parity.py::test_gto_unnormalize."""
