@@ -439,12 +439,45 @@ __host__ __device__ inline size_t attn_bwd_lds_bytes(int L, int G) {
     return ((size_t)4 * L * LD + 2 * big + 4 * G + 2 * C + 2 * (AB_THREADS / 64) * G + 8 * C) * 4;
 }
 
-// one 16x16 output tile: acc += sum_k A(m, k) B(k, n) for this lane's (m or n) = tile*16 + (lane & 15), k = 4*step + (lane >> 4)
-template <class FA, class FB>
-__device__ __forceinline__ f32x4 ab_tile(int steps, int kq, FA fa, FB fb, f32x4 acc) {
-#pragma unroll 4
-    for (int k = 0; k < steps; ++k) acc = mfma16(fa(4 * k + kq), fb(4 * k + kq), acc);
-    return acc;
+// MFMA tile helpers: a lane's operand index is tile*16 + (lane & 15), its k index 4*step + (lane >> 4).  NT output tiles
+// advance together per k-step (independent accumulators, one shared fragment) so LDS / global latency overlaps the MFMAs.
+template <int NT, class FA, class FB>
+__device__ __forceinline__ void ab_shareB(int steps, int kq, FA fa, FB fb, f32x4 (&acc)[NT]) {   // acc[i] += A_i B
+#pragma unroll 2
+    for (int s = 0; s < steps; ++s) {
+        const int k = 4 * s + kq;
+        const float b = fb(k);
+        float av[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) av[i] = fa(i, k);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = mfma16(av[i], b, acc[i]);
+    }
+}
+template <int NT, class FA, class FB>
+__device__ __forceinline__ void ab_shareA(int steps, int kq, FA fa, FB fb, f32x4 (&acc)[NT]) {   // acc[i] += A B_i
+#pragma unroll 2
+    for (int s = 0; s < steps; ++s) {
+        const int k = 4 * s + kq;
+        const float av = fa(k);
+        float bv[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) bv[i] = fb(i, k);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = mfma16(av, bv[i], acc[i]);
+    }
+}
+// same with the shared B fragment of a K = 64 contraction already in registers (a global weight column, loaded up front)
+template <int NT, class FA>
+__device__ __forceinline__ void ab_regB(int kq, FA fa, const float (&bw)[16], f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float av[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) av[i] = fa(i, 4 * s + kq);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = mfma16(av[i], bw[s], acc[i]);
+    }
 }
 
 template <int C>
@@ -500,25 +533,42 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
             for (int p = wave; p < L; p += NW) O[p * LD + lane] = (O[p * LD + lane] - m) * rs * gam[lane] + bet[lane];
         }
         __syncthreads();
-        // ---- A: q, k, v = xn W + b
-        for (int t = wave; t < 3 * MT * CT; t += NW) {
-            const int which = t / (MT * CT), r = t - which * MT * CT, mt = r / CT, nt = r - mt * CT;
-            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col;
-            const float* W = a.W[which];
-            f32x4 acc = ab_tile(C / 4, kq, [&](int k) { return O[m * LD + k]; }, [&](int k) { return ldg1(W + k * C + nn); }, f32x4{0.f, 0.f, 0.f, 0.f});
-            float* dst = which == 0 ? Q : which == 1 ? K : V;
-            const float bias = ldg1(a.b[which] + nn);
+        // wave roles for [L][C] outputs: channel tile wn, row tiles wg, wg+2, wg+4 (three accumulators share a B fragment)
+        const int wn = wave & 3, wg = wave >> 2;
+        int mrow[3];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) dst[mm * LD + nn] = acc[r4] + bias; }
+        for (int i = 0; i < 3; ++i) mrow[i] = min((wg + 2 * i) * 16 + col, L - 1);
+        const int ncol = wn * 16 + col;
+        auto store3 = [&](float* dst, const f32x4 (&acc)[3], float addv) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { const int mm = (wg + 2 * i) * 16 + kq * 4 + r4; if (mm < L) dst[mm * LD + ncol] = acc[i][r4] + addv; }
+        };
+        // ---- A: q, k, v = xn W + b   (the weight column of this wave's channel tile is loaded to registers up front)
+#pragma unroll 1
+        for (int which = 0; which < 3; ++which) {
+            const float* W = a.W[which];
+            float bw[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) bw[st] = ldg1(W + (4 * st + kq) * C + ncol);
+            f32x4 acc[3] = {};
+            ab_regB<3>(kq, [&](int i, int k) { return O[mrow[i] * LD + k]; }, bw, acc);
+            store3(which == 0 ? Q : which == 1 ? K : V, acc, ldg1(a.b[which] + ncol));
         }
         __syncthreads();
-        // ---- B: P = softmax(Q K^T * scale)
-        for (int t = wave; t < MT * MT; t += NW) {
-            const int mt = t / MT, nt = t - mt * MT;
-            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col, nc = min(nn, L - 1);
-            f32x4 acc = ab_tile(C / 4, kq, [&](int k) { return Q[m * LD + k]; }, [&](int k) { return K[nc * LD + k]; }, f32x4{0.f, 0.f, 0.f, 0.f});
+        // ---- B: P = softmax(Q K^T * scale): wave w < MT owns key tile w for all row tiles
+        if (wave < MT) {
+            const int nn = wave * 16 + col, nc = min(nn, L - 1);
+            f32x4 acc[6] = {};
+            int mr[6];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L && nn < L) P[mm * LP + nn] = acc[r4] * a.scale; }
+            for (int i = 0; i < 6; ++i) mr[i] = min(i * 16 + col, L - 1);
+            ab_shareB<6>(C / 4, kq, [&](int i, int k) { return Q[mr[i] * LD + k]; }, [&](int k) { return K[nc * LD + k]; }, acc);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { const int mm = i * 16 + kq * 4 + r4; if (mm < L && nn < L) P[mm * LP + nn] = acc[i][r4] * a.scale; }
         }
         __syncthreads();
         for (int r = wave; r < L; r += NW) {
@@ -534,64 +584,47 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
         }
         __syncthreads();
         // ---- C: O = P V
-        for (int t = wave; t < MT * CT; t += NW) {
-            const int mt = t / CT, nt = t - mt * CT;
-            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col;
-            f32x4 acc = ab_tile(KL, kq, [&](int k) { return k < L ? P[m * LP + k] : 0.f; }, [&](int k) { return k < L ? V[k * LD + nn] : 0.f; },
-                                f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) O[mm * LD + nn] = acc[r4]; }
+        {
+            f32x4 acc[3] = {};
+            ab_shareB<3>(KL, kq, [&](int i, int k) { return k < L ? P[mrow[i] * LP + k] : 0.f; }, [&](int k) { return k < L ? V[k * LD + ncol] : 0.f; }, acc);
+            store3(O, acc, 0.f);
         }
         __syncthreads();
-        // ---- D: dW3 += O^T gH;  gO = gH W3^T (registers, then over O)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = wave * 2 + i, jt = t / CT, ct = t - jt * CT;
-            const int j = jt * 16 + col, cc = ct * 16 + col;
-            dw3[i] = ab_tile(KL, kq, [&](int k) { return k < L ? O[k * LD + j] : 0.f; }, [&](int k) { return k < L ? GP[k * LD + cc] : 0.f; }, dw3[i]);
+        // ---- D: dW3 += O^T gH (two channel tiles share the O^T fragment);  gO = gH W3^T (registers, then over O)
+        {
+            const int j = (wave >> 1) * 16 + col, c0 = (wave & 1) * 32 + col;
+            ab_shareA<2>(KL, kq, [&](int k) { return k < L ? O[k * LD + j] : 0.f; }, [&](int i, int k) { return k < L ? GP[k * LD + c0 + 16 * i] : 0.f; }, dw3);
         }
         for (int p = wave; p < L; p += NW) dbh += GP[p * LD + lane];
-        f32x4 hold[6];
+        f32x4 hold[6] = {};
+        {
+            const float* W3 = a.W[3];
+            float bw[16];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t = wave + i * NW;
-            hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < MT * CT) {
-                const int mt = t / CT, nt = t - mt * CT;
-                const int m = min(mt * 16 + col, L - 1), j = nt * 16 + col;
-                const float* W3 = a.W[3];
-                hold[i] = ab_tile(C / 4, kq, [&](int k) { return GP[m * LD + k]; }, [&](int k) { return ldg1(W3 + j * C + k); }, hold[i]);
-            }
+            for (int st = 0; st < 16; ++st) bw[st] = ldg1(W3 + ncol * C + 4 * st + kq);
+            f32x4 (&h3)[3] = reinterpret_cast<f32x4(&)[3]>(hold[0]);
+            ab_regB<3>(kq, [&](int i, int k) { return GP[mrow[i] * LD + k]; }, bw, h3);
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t = wave + i * NW;
-            if (t < MT * CT) {
-                const int mt = t / CT, nt = t - mt * CT, j = nt * 16 + col;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) O[mm * LD + j] = hold[i][r4]; }
-            }
-        }
+        store3(O, reinterpret_cast<f32x4(&)[3]>(hold[0]), 0.f);
         __syncthreads();
         // ---- E: gP = gO V^T -> GP (gH is dead);  gV = P^T gO -> registers
-        for (int t = wave; t < MT * MT; t += NW) {
-            const int mt = t / MT, nt = t - mt * MT;
-            const int m = min(mt * 16 + col, L - 1), nn = nt * 16 + col, nc = min(nn, L - 1);
-            f32x4 acc = ab_tile(C / 4, kq, [&](int k) { return O[m * LD + k]; }, [&](int k) { return V[nc * LD + k]; }, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (wave < MT) {
+            const int nn = wave * 16 + col, nc = min(nn, L - 1);
+            f32x4 acc[6] = {};
+            int mr[6];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L && nn < L) GP[mm * LP + nn] = acc[r4]; }
+            for (int i = 0; i < 6; ++i) mr[i] = min(i * 16 + col, L - 1);
+            ab_shareB<6>(C / 4, kq, [&](int i, int k) { return O[mr[i] * LD + k]; }, [&](int k) { return V[nc * LD + k]; }, acc);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { const int mm = i * 16 + kq * 4 + r4; if (mm < L && nn < L) GP[mm * LP + nn] = acc[i][r4]; }
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t = wave + i * NW;
-            hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < MT * CT) {
-                const int mt = t / CT, nt = t - mt * CT;
-                const int j = min(mt * 16 + col, L - 1), cc = nt * 16 + col;
-                hold[i] = ab_tile(KL, kq, [&](int k) { return k < L ? P[k * LP + j] : 0.f; }, [&](int k) { return k < L ? O[k * LD + cc] : 0.f; }, hold[i]);
-            }
-        }
+        for (int i = 0; i < 3; ++i) hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab_shareB<3>(KL, kq, [&](int i, int k) { return k < L ? P[k * LP + mrow[i]] : 0.f; }, [&](int k) { return k < L ? O[k * LD + ncol] : 0.f; },
+                     reinterpret_cast<f32x4(&)[3]>(hold[0]));
         __syncthreads();
         // ---- F: gS = P * (gP - rowsum(gP * P)) * scale over GP;  O <- gV
         for (int r = wave; r < L; r += NW) {
@@ -602,63 +635,44 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
             if (lane < L) GP[r * LP + lane] = p0 * (g0 - d) * a.scale;
             if (lane + 64 < L) GP[r * LP + lane + 64] = p1 * (g1 - d) * a.scale;
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t = wave + i * NW;
-            if (t < MT * CT) {
-                const int mt = t / CT, nt = t - mt * CT, cc = nt * 16 + col;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) O[mm * LD + cc] = hold[i][r4]; }
-            }
-        }
+        store3(O, reinterpret_cast<f32x4(&)[3]>(hold[0]), 0.f);
         __syncthreads();
         // ---- G: gQ = gS K, gK = gS^T Q -> registers;  P region <- xhat
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int t = wave + i * NW;
-            hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (t < 2 * MT * CT) {
-                const int which = t / (MT * CT), r = t - which * MT * CT, mt = r / CT, nt = r - mt * CT;
-                const int m = min(mt * 16 + col, L - 1), cc = nt * 16 + col;
-                if (which == 0) hold[i] = ab_tile(KL, kq, [&](int k) { return k < L ? GP[m * LP + k] : 0.f; }, [&](int k) { return k < L ? K[k * LD + cc] : 0.f; }, hold[i]);
-                else hold[i] = ab_tile(KL, kq, [&](int k) { return k < L ? GP[k * LP + m] : 0.f; }, [&](int k) { return k < L ? Q[k * LD + cc] : 0.f; }, hold[i]);
-            }
-        }
+        for (int i = 0; i < 6; ++i) hold[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab_shareB<3>(KL, kq, [&](int i, int k) { return k < L ? GP[mrow[i] * LP + k] : 0.f; }, [&](int k) { return k < L ? K[k * LD + ncol] : 0.f; },
+                     reinterpret_cast<f32x4(&)[3]>(hold[0]));
+        ab_shareB<3>(KL, kq, [&](int i, int k) { return k < L ? GP[k * LP + mrow[i]] : 0.f; }, [&](int k) { return k < L ? Q[k * LD + ncol] : 0.f; },
+                     reinterpret_cast<f32x4(&)[3]>(hold[3]));
         {
             const float m = stat[4 * (lane / Cg)], rs = stat[4 * (lane / Cg) + 1];
             for (int p = wave; p < L; p += NW) P[p * LD + lane] = (ldg1(xg + p * C + lane) - m) * rs;
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int t = wave + i * NW;
-            if (t < 2 * MT * CT) {
-                const int which = t / (MT * CT), r = t - which * MT * CT, mt = r / CT, nt = r - mt * CT, cc = nt * 16 + col;
-                float* dst = which == 0 ? Q : K;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) dst[mm * LD + cc] = hold[i][r4]; }
-            }
-        }
+        store3(Q, reinterpret_cast<f32x4(&)[3]>(hold[0]), 0.f);
+        store3(K, reinterpret_cast<f32x4(&)[3]>(hold[3]), 0.f);
         __syncthreads();
-        // ---- H: Q = gQ, K = gK, O = gV.  dW0..2 += xn^T g.;  bias partials;  V <- gxn = gQ W0^T + gK W1^T + gV W2^T
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int t = wave * 6 + i, which = t / (CT * CT), r = t - which * CT * CT, jt = r / CT, ct = r - jt * CT;
-            const int j = jt * 16 + col, cc = ct * 16 + col;
+        // ---- H: Q = gQ, K = gK, O = gV.  dW0..2 += xn^T g. (six tiles share the xn^T fragment of input-channel tile wn:
+        //      tile i = which*2 + c, channel tile 2*wg + c);  bias partials;  V <- gxn = gQ W0^T + gK W1^T + gV W2^T
+        {
+            const int j = wn * 16 + col, c0 = wg * 32 + col;
             const float gj = gam[j], bj = bet[j];
-            const float* src = which == 0 ? Q : which == 1 ? K : O;
-            dw012[i] = ab_tile(KL, kq, [&](int k) { return k < L ? P[k * LD + j] * gj + bj : 0.f; }, [&](int k) { return k < L ? src[k * LD + cc] : 0.f; }, dw012[i]);
+            ab_shareA<6>(KL, kq, [&](int k) { return k < L ? P[k * LD + j] * gj + bj : 0.f; },
+                         [&](int i, int k) { const float* src = (i >> 1) == 0 ? Q : (i >> 1) == 1 ? K : O; return k < L ? src[k * LD + c0 + 16 * (i & 1)] : 0.f; }, dw012);
         }
         for (int p = wave; p < L; p += NW) { dbq += Q[p * LD + lane]; dbk += K[p * LD + lane]; dbv += O[p * LD + lane]; }
-        for (int t = wave; t < MT * CT; t += NW) {
-            const int mt = t / CT, nt = t - mt * CT;
-            const int m = min(mt * 16 + col, L - 1), j = nt * 16 + col;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = ab_tile(C / 4, kq, [&](int k) { return Q[m * LD + k]; }, [&](int k) { return ldg1(a.W[0] + j * C + k); }, acc);
-            acc = ab_tile(C / 4, kq, [&](int k) { return K[m * LD + k]; }, [&](int k) { return ldg1(a.W[1] + j * C + k); }, acc);
-            acc = ab_tile(C / 4, kq, [&](int k) { return O[m * LD + k]; }, [&](int k) { return ldg1(a.W[2] + j * C + k); }, acc);
+        {
+            f32x4 acc[3] = {};
+#pragma unroll 1
+            for (int which = 0; which < 3; ++which) {
+                const float* W = a.W[which];
+                const float* src = which == 0 ? Q : which == 1 ? K : O;
+                float bw[16];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { const int mm = mt * 16 + kq * 4 + r4; if (mm < L) V[mm * LD + j] = acc[r4]; }
+                for (int st = 0; st < 16; ++st) bw[st] = ldg1(W + ncol * C + 4 * st + kq);
+                ab_regB<3>(kq, [&](int i, int k) { return src[mrow[i] * LD + k]; }, bw, acc);
+            }
+            store3(V, acc, 0.f);
         }
         __syncthreads();
         // ---- J: GroupNorm backward (no activation), residual branch
@@ -681,19 +695,16 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
         }
         __syncthreads();
     }
-    // ---- flush the per-workgroup parameter gradients
+    // ---- flush the per-workgroup parameter gradients (tile roles as in phases D and H)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = wave * 2 + i, jt = t / CT, ct = t - jt * CT;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) atomicAdd(a.dW[3] + (jt * 16 + kq * 4 + r4) * C + ct * 16 + col, dw3[i][r4]);
-    }
+        for (int r4 = 0; r4 < 4; ++r4) atomicAdd(a.dW[3] + ((wave >> 1) * 16 + kq * 4 + r4) * C + (wave & 1) * 32 + 16 * i + col, dw3[i][r4]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int t = wave * 6 + i, which = t / (CT * CT), r = t - which * CT * CT, jt = r / CT, ct = r - jt * CT;
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) atomicAdd(a.dW[which] + (jt * 16 + kq * 4 + r4) * C + ct * 16 + col, dw012[i][r4]);
-    }
+        for (int r4 = 0; r4 < 4; ++r4)
+            atomicAdd(a.dW[i >> 1] + ((wave & 3) * 16 + kq * 4 + r4) * C + (wave >> 2) * 32 + 16 * (i & 1) + col, dw012[i][r4]);
     float* outs[6] = {a.db[0], a.db[1], a.db[2], a.db[3], a.dgamma, a.dbeta};
     const float vals[6] = {dbq, dbk, dbv, dbh, dgm, dbt};
     for (int q = 0; q < 6; ++q) {
