@@ -9,6 +9,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char rdmi_lds[];
 
 #define RDMI_THREADS 256
 
+// instruction-scheduling fence: nothing is moved across it by the compiler's scheduler (no code is emitted)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RDMI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RDMI_SCHED_FENCE() ((void)0)
+#endif
+
 __device__ __forceinline__ float silu_f(float y) { return __fdividef(y, 1.0f + __expf(-y)); }
 
 // v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fma chain), 1024 MAC per wave-instruction.
@@ -16,6 +23,15 @@ __device__ __forceinline__ float silu_f(float y) { return __fdividef(y, 1.0f + _
 // result: col = l&15, rows (l>>4)*4 + r in element r.
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4x1 outer products (block b = l>>2), exact fp32, 13 cycles per issue
+// (measured, scripts/micro/mfma4.hip; the 16x16x4 form takes 32).  Lane 4b+i supplies A_b[i], lane 4b+j supplies B_b[j];
+// element i of lane 4b+j receives D_b[i][j].  Used where an image has <= 4 pixels: with lane l reading the SAME
+// operands as for mfma16 except A row = l&3, block (l>>2)&3 covers columns 4*((l>>2)&3)..+3 and l>>4 selects the k
+// group, so the four k groups are summed across lanes l, l^16, l^32, l^48 at the end.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
 // cube.reflect (RD/cube.py:34-49): floor-mod 2 then fold (1,2] onto [0,1).

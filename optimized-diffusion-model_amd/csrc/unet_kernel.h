@@ -266,7 +266,7 @@ __device__ __forceinline__ int arow(const short* tab, int m, int lds_off, int rs
 //    rows are the zero row, so there is no tail code (instruction-cache footprint matters: the whole interpreter
 //    must stay resident in the 64 KiB I-cache or every op transition refetches cold code);
 //  * A fragments are read from LDS one step ahead of the MFMAs that consume them.
-template <int NMT, int PF>
+template <int NMT, int PF, bool M4 = false>
 __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int n, int mt0, int WM, int nt, int lane, long long* fine) {
     const int lrow = lane & 15, kq = lane >> 4;
     if (fine) fine[0] = clock64();
@@ -288,7 +288,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
     for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int mrow[NMT];
 #pragma unroll
-    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + lrow;
+    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + (M4 ? (lane & 3) : lrow);     // M4: images of <= 4 pixels
     // epilogue operands are fetched now so their global latency hides under the GEMM
     float add = 0.f;
     if (col < o_Cout) {
@@ -305,10 +305,15 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
 #pragma unroll
         for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nsteps - 1) * bstride);
         int ph = 0, ch = 0;
-        int abase[NMT];
+        // row offsets of the current tap and, one tap AHEAD, of the next one: the table lookup (LDS read + address math)
+        // of a tap transition is issued a whole tap early, so the transition itself is a register move
+        int abase[NMT], anext[NMT];
 #pragma unroll
-        for (int i = 0; i < NMT; ++i)
+        for (int i = 0; i < NMT; ++i) {
             abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
+            anext[i] = o_ntap > 1 ? arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word + 1)), mrow[i], m_lds, m_rs, zero_off) + kq * 16
+                                  : zero_off + kq * 16;
+        }
         f32x4 afn[NMT];
 #pragma unroll
         for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i]);
@@ -322,18 +327,25 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
                 // advance to the next step and issue its A reads before this step's MFMAs
                 if (++ch == nch) {
                     ch = 0; ++ph;
-                    if (ph < o_ntap) {
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) abase[i] = anext[i];
+                    if (ph + 1 < o_ntap) {
 #pragma unroll
                         for (int i = 0; i < NMT; ++i)
-                            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word + ph)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
+                            anext[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word + ph + 1)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
                     } else {
 #pragma unroll
-                        for (int i = 0; i < NMT; ++i) abase[i] = zero_off + kq * 16;     // padding steps contribute 0
+                        for (int i = 0; i < NMT; ++i) anext[i] = zero_off + kq * 16;     // padding steps contribute 0
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
-                if (NMT == 1) {     // single row tile: alternate two accumulators so the MFMAs are not a dependent chain
+                RDMI_SCHED_FENCE();   // keep those LDS reads ABOVE this step's MFMAs (the scheduler otherwise sinks them below
+                                      // and the next step starts with a full lgkmcnt(0) wait on a just-issued read)
+                if (M4) {           // <= 4 rows: the 4x4x1 multi-block form wastes no rows (13 vs 32 cycles per MFMA, see mfma4)
+                    acc[0] = mfma4(af[0][0], ring[p][0], acc[0]); acc2 = mfma4(af[0][1], ring[p][1], acc2);
+                    acc[0] = mfma4(af[0][2], ring[p][2], acc[0]); acc2 = mfma4(af[0][3], ring[p][3], acc2);
+                } else if (NMT == 1) {     // single row tile: alternate two accumulators so the MFMAs are not a dependent chain
                     acc[0] = mfma16(af[0][0], ring[p][0], acc[0]); acc2 = mfma16(af[0][1], ring[p][1], acc2);
                     acc[0] = mfma16(af[0][2], ring[p][2], acc[0]); acc2 = mfma16(af[0][3], ring[p][3], acc2);
                 } else {
@@ -347,6 +359,15 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
         }
     }
     if (NMT == 1) acc[0] += acc2;
+    if (M4) {               // sum the four k groups: afterwards every lane holds D[row r][col lrow], the kq == 0 lanes' share
+#pragma unroll              // of the 16x16x4 result layout, so the epilogue below is unchanged (other lanes' rows are >= 4)
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[0][r];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[0][r] = v;
+        }
+    }
     if (fine) fine[4] = clock64();
     // ---- epilogue: three destinations, each its own (wave-uniform) branch so LDS stores stay ds_write and global
     //      stores stay global_store (a merged pointer would degrade both to flat_store)
@@ -431,7 +452,10 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
         for (int mt0 = wm; mt0 < mtiles; mt0 += 4 * WM) {
             const int left = (mtiles - mt0 + WM - 1) >> lWM;
             switch (left >= 4 ? 4 : left) {
-                case 1: fconv_wave<1, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 1:
+                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<1, 8, true>(w, u, n, mt0, WM, nt, lane, fine);
+                    else fconv_wave<1, 8>(w, u, n, mt0, WM, nt, lane, fine);
+                    break;
                 case 2: fconv_wave<2, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
                 case 3: fconv_wave<3, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
                 case 4: fconv_wave<4, 4>(w, u, n, mt0, WM, nt, lane, fine); break;

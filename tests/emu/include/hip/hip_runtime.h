@@ -82,6 +82,18 @@ inline f32x4_emu __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4_em
     return d;
 }
 
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks (block = l>>2); lane 4b+i supplies A_b[i], lane 4b+j supplies B_b[j];
+// D_b[i][j] lands in element i of lane 4b+j (layout probed on gfx950: scripts/micro/mfma4.hip).
+inline f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu c, int, int, int) {
+    float ab[2] = {a, b};
+    const float* all = reinterpret_cast<const float*>(emu::wave_exchange(ab, sizeof(ab)));
+    int l = emu::lane_id();
+    int blk = l >> 2;
+    f32x4_emu d = c;
+    for (int i = 0; i < 4; ++i) d[i] = fmaf(all[2 * (4 * blk + i)], all[2 * l + 1], c[i]);
+    return d;
+}
+
 inline long long clock64() { return 0; }
 inline float atomicAdd(float* p, float v) {   // workgroups run on parallel OS threads: a real atomic
     unsigned* u = reinterpret_cast<unsigned*>(p);
