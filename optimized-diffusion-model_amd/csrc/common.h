@@ -34,6 +34,50 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// All-reduce over the 16 lanes of a DPP row (lanes 16r..16r+15) in four VALU-DPP steps (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror).  __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round trip of ~100+ cycles per
+// step, four to six dependent steps per reduction); these stay in the VALU.  Each step adds the same two partial sums
+// the xor-4 / xor-8 butterfly would, so the result is bitwise that of the xor butterfly in the order 1, 2, 4, 8
+// (which is what the host/emulator build executes).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v);
+    return v;
+}
+// value of lane `l` (compile-time) as a wave-uniform float
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+#else
+__device__ __forceinline__ float row16_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float row8_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __shfl(v, l); }
+#endif
+// sum over aligned groups of 32 / 64 lanes: row sums, then the (row-uniform) sums of the other rows by v_readlane
+__device__ __forceinline__ float group32_sum(float v, int lane) {
+    const float r = row16_sum(v);
+    const float s0 = lane_bcast(r, 0), s1 = lane_bcast(r, 16), s2 = lane_bcast(r, 32), s3 = lane_bcast(r, 48);
+    return lane < 32 ? s0 + s1 : s2 + s3;
+}
+__device__ __forceinline__ float group64_sum(float v) {
+    const float r = row16_sum(v);
+    return (lane_bcast(r, 0) + lane_bcast(r, 16)) + (lane_bcast(r, 32) + lane_bcast(r, 48));
+}
+
 // cube.reflect (RD/cube.py:34-49): floor-mod 2 then fold (1,2] onto [0,1).
 // x - 2*floor(x/2) is exact for the even multiple and rounds once, like torch.remainder.
 __device__ __forceinline__ float reflect_f(float x) {

@@ -70,7 +70,8 @@ struct UnetArgs {
     const float* x_in; int x_mod;                 // network input [x_mod or NB][HW][channels] (GATHER with a_off == -2)
     float* out;                                   // network output [NB][HW][channels]   (CONV dst_kind 2, g_out null)
     int NB;
-    int dbg;                                      // diagnostic ablations (0 in production): 1 = no ring refills, 2 = no MFMA
+    int dbg;                                      // diagnostic ablations (0 in production; results are wrong when set): bit 2 skips GN
+                                                  // bodies, bit 3 CONV, bit 4 ATTN, bit 5 GATHER/STORE (scripts/gpu_ablate.py)
     long long* stamps;                            // diagnostic: per-op shader-clock stamps of workgroup 0 (null in production)
 };
 
@@ -154,23 +155,13 @@ __device__ __forceinline__ void fop_store(const OpW& w, int n, int tid) {
     }
 }
 
-// xor-shuffle sum over groups of T lanes with COMPILE-TIME masks (DPP / permlane forms instead of ds_bpermute)
-template <int T>
-__device__ __forceinline__ float group_sum(float v) {
-    if (T >= 64) v += __shfl_xor(v, 32);
-    if (T >= 32) v += __shfl_xor(v, 16);
-    if (T >= 16) v += __shfl_xor(v, 8);
-    if (T >= 8) v += __shfl_xor(v, 4);
-    if (T >= 4) v += __shfl_xor(v, 2);
-    if (T >= 2) v += __shfl_xor(v, 1);
-    return v;
-}
-__device__ __forceinline__ float group_sum_rt(float v, int logT) {
+// sum over aligned groups of 2^logT lanes (8, 16, 32 or 64): DPP row reductions (common.h), no LDS-crossbar shuffles
+__device__ __forceinline__ float group_sum_rt(float v, int logT, int lane) {
     switch (logT) {
-        case 6: return group_sum<64>(v);
-        case 5: return group_sum<32>(v);
-        case 4: return group_sum<16>(v);
-        default: return group_sum<8>(v);
+        case 6: return group64_sum(v);
+        case 5: return group32_sum(v, lane);
+        case 4: return row16_sum(v);
+        default: return row8_sum(v);
     }
 }
 
@@ -178,7 +169,7 @@ __device__ __forceinline__ float group_sum_rt(float v, int logT) {
 // group's values held in REGISTERS between the passes (one LDS read per element), T lanes per group reduced by
 // xor-shuffles; the affine parameters of this work-item's fixed channel quad are prefetched by the caller one op
 // ahead (pgm/pbt) so their global latency never sits on the op-transition path.
-__device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4 pgm, f32x4 pbt) {
+__device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4 pgm, f32x4 pbt, int dbg = 0) {
     float* X = lds_f(OPI(w, dst_off));
     const int src_off = OPI(w, src_off);
     const float* S = src_off >= 0 ? lds_f(src_off) : X;
@@ -194,6 +185,7 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
     constexpr int MAXR = 6;
     f32x4 v0[MAXR], v1[MAXR];
     float sum = 0.f;
+    if (!(dbg & 64)) {
     const int q4 = (Cg + 3) >> 2;                     // float4 per row of the group: 1 (Cg=4), 2 (Cg=6: 4+2, Cg=8)
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
@@ -210,7 +202,7 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
             sum += (v0[k][0] + v0[k][1]) + (v0[k][2] + v0[k][3]) + (v1[k][0] + v1[k][1]) + (v1[k][2] + v1[k][3]);
         }
     }
-    sum = group_sum_rt(sum, logT);
+    sum = group_sum_rt(sum, logT, tid & 63);
     const float mean = sum * inv_cnt;
     float sq = 0.f;
 #pragma unroll
@@ -221,15 +213,16 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
             for (int cc = 4; cc < Cg; ++cc) { const float d = v1[k][cc - 4] - mean; sq += d * d; }
         }
     }
-    sq = group_sum_rt(sq, logT);
+    sq = group_sum_rt(sq, logT, tid & 63);
     if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
+    }
     // fixed channel quad per work-item: rows advance by rstep; work-items beyond rstep*c4n idle (C = 192)
     const int c4n = o_C >> 2;
     const int rstep = (UW_THREADS * mg_c4n) >> 16;      // floor(512 / c4n)
     const int r0 = (tid * mg_c4n) >> 16, c = (tid - r0 * c4n) << 2;
     const bool active = r0 < rstep;
     __syncthreads();
-    if (active) {
+    if (active && !(dbg & 128)) {
         f32x4 mu, rstd;
         for (int j = 0; j < 4; ++j) { const int gg = ((c + j) * mg_Cg) >> 16; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
         for (int row = r0; row < o_rows; row += rstep) {
@@ -504,7 +497,7 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
 #pragma unroll
             for (int t = 0; t < 6; ++t)
                 if (t < mtiles && t * 16 + lrow < L) { s[t][r] *= o.att_scale; mx = fmaxf(mx, s[t][r]); }
-            for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+            mx = row16_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -513,7 +506,7 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
                     s[t][r] = e;
                     sum += e;
                 }
-            for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+            sum = row16_sum(sum);
             const float inv = 1.0f / sum;
             const int row = mt * 16 + kq * 4 + r;
             if (row < L) {
@@ -586,10 +579,11 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         f32x4 ngm = pgm, nbt = pbt;
         if (pc + 1 < u.nops) gn_prefetch(nxt, tid, ngm, nbt);
         if (fine) fine[3] = clock64();
-        switch (kind) {
+        const int skip = u.dbg ? ((kind == FOP_GN ? 4 : kind == FOP_CONV ? 8 : kind == FOP_ATTN ? 16 : 32) & u.dbg) : 0;
+        switch (skip ? -1 : kind) {
             case FOP_GATHER: fop_gather(cur, u, n, tid); break;
             case FOP_STORE: fop_store(cur, n, tid); break;
-            case FOP_GN: fop_gn(cur, stat, tid, pgm, pbt); break;
+            case FOP_GN: fop_gn(cur, stat, tid, pgm, pbt, u.dbg); break;
             case FOP_CONV: fop_conv(cur, u, n, wave, lane, fine); break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             default: break;

@@ -26,6 +26,6 @@ prof = ctx.get_profile()
 print(json.dumps({'wall_ms_per_update': wall*1e3/40, 'k': {p['kernel']: round(1e3*p['ms']/max(p['launches'],1),1) for p in prof}}))
 ''' % (ROOT, ROOT)
 for dbg in sys.argv[1:] or ['0', '1', '2', '3']:
-    env = dict(os.environ, RDMI_DBG=dbg)
+    env = dict(os.environ, RDMI_UDBG=dbg)
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
-    print('RDMI_DBG=' + dbg, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:], flush=True)
+    print('RDMI_UDBG=' + dbg, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:], flush=True)
