@@ -186,32 +186,41 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
     f32x4 v0[MAXR], v1[MAXR];
     float sum = 0.f;
     if (!(dbg & 64)) {
-    const int q4 = (Cg + 3) >> 2;                     // float4 per row of the group: 1 (Cg=4), 2 (Cg=6: 4+2, Cg=8)
+    // Branch-free over rows: every lane loads its (clamped) rows back to back -- all reads in flight before the first
+    // wait -- and rows beyond the tensor / channels beyond the group are masked out of the sums.  Only the group width
+    // (Cg = 4, 8: one or two 16-byte reads; Cg = 6: three 8-byte reads, groups start at 8-byte boundaries) branches,
+    // and that branch is wave-uniform.
+    float rw[MAXR];                                    // 1 for a real row of this lane, else 0
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
         const int v = sub + k * T;
-        v0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (v < o_rows) {
-            if ((Cg & 3) == 0) {
-                v0[k] = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs);
-                if (q4 > 1) v1[k] = *reinterpret_cast<const f32x4*>(base + (size_t)v * srs + 4);
-            } else {                                   // Cg = 6 (C = 192): groups start at 8-byte, not 16-byte, boundaries
-                for (int cc = 0; cc < 4; ++cc) v0[k][cc] = base[(size_t)v * srs + cc];
-                for (int cc = 4; cc < Cg; ++cc) v1[k][cc - 4] = base[(size_t)v * srs + cc];
-            }
-            sum += (v0[k][0] + v0[k][1]) + (v0[k][2] + v0[k][3]) + (v1[k][0] + v1[k][1]) + (v1[k][2] + v1[k][3]);
+        rw[k] = v < o_rows ? 1.f : 0.f;
+        const float* p = base + (size_t)min(v, o_rows - 1) * srs;
+        if ((Cg & 3) == 0) {
+            v0[k] = *reinterpret_cast<const f32x4*>(p);
+            v1[k] = Cg > 4 ? *reinterpret_cast<const f32x4*>(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            typedef float f32x2 __attribute__((vector_size(8)));
+            const f32x2 a0 = *reinterpret_cast<const f32x2*>(p), a1 = *reinterpret_cast<const f32x2*>(p + 2), a2 = *reinterpret_cast<const f32x2*>(p + 4);
+            v0[k] = f32x4{a0[0], a0[1], a1[0], a1[1]};
+            v1[k] = f32x4{a2[0], a2[1], 0.f, 0.f};
         }
     }
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k)
+        sum += rw[k] * ((v0[k][0] + v0[k][1]) + (v0[k][2] + v0[k][3]) + (v1[k][0] + v1[k][1]) + (v1[k][2] + v1[k][3]));
     sum = group_sum_rt(sum, logT, tid & 63);
     const float mean = sum * inv_cnt;
     float sq = 0.f;
+    const float m4 = Cg > 4 ? 1.f : 0.f, m6 = Cg > 6 ? 1.f : 0.f;      // which of the second quad's channels exist
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
-        const int v = sub + k * T;
-        if (v < o_rows) {
-            for (int cc = 0; cc < 4; ++cc) { const float d = v0[k][cc] - mean; sq += d * d; }
-            for (int cc = 4; cc < Cg; ++cc) { const float d = v1[k][cc - 4] - mean; sq += d * d; }
-        }
+        float q = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) { const float d = v0[k][cc] - mean; q += d * d; }
+        const float d4 = v1[k][0] - mean, d5 = v1[k][1] - mean, d6 = v1[k][2] - mean, d7 = v1[k][3] - mean;
+        q += m4 * (d4 * d4 + d5 * d5) + m6 * (d6 * d6 + d7 * d7);
+        sq += rw[k] * q;
     }
     sq = group_sum_rt(sq, logT, tid & 63);
     if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
@@ -382,9 +391,14 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
 #pragma unroll
             for (int i = 0; i < NMT; ++i) {
                 const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+                if ((mt0 + i * WM) * 16 + 16 <= o_rows) {          // whole tile inside the image (wave-uniform): no per-row guards
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + lc] = (acc[i][r] + add) * o_scale;
+                    for (int r = 0; r < 4; ++r) dstp[(row0 + r) * o_dst_rs + lc] = (acc[i][r] + add) * o_scale;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + lc] = (acc[i][r] + add) * o_scale;
+                }
             }
         }
     } else if (o_kind == 1) {                 // LDS, transposed [col][row]; all padded rows written (finite)
@@ -408,8 +422,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
             for (int i = 0; i < NMT; ++i) {
                 const int row0 = (mt0 + i * WM) * 16 + kq * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < o_rows) rv[i][r] = resp[(row0 + r) * o_resid_rs + col];
+                for (int r = 0; r < 4; ++r) rv[i][r] = resp[min(row0 + r, o_rows - 1) * o_resid_rs + col];   // unguarded: all reads in flight at once
             }
         }
         if (o_kind == 0) {
@@ -417,18 +430,28 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
 #pragma unroll
             for (int i = 0; i < NMT; ++i) {
                 const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+                if ((mt0 + i * WM) * 16 + 16 <= o_rows) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + col] = (acc[i][r] + add + rv[i][r]) * o_scale;
+                    for (int r = 0; r < 4; ++r) dstp[(row0 + r) * o_dst_rs + col] = (acc[i][r] + add + rv[i][r]) * o_scale;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + col] = (acc[i][r] + add + rv[i][r]) * o_scale;
+                }
             }
         } else {
             float* gp = (o_gout ? o_gout : u.out) + (size_t)n * o_rows * o_Cout + col;
 #pragma unroll
             for (int i = 0; i < NMT; ++i) {
                 const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+                if ((mt0 + i * WM) * 16 + 16 <= o_rows) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < o_rows) stg1(gp + (row0 + r) * o_Cout, (acc[i][r] + add + rv[i][r]) * o_scale);
+                    for (int r = 0; r < 4; ++r) stg1(gp + (row0 + r) * o_Cout, (acc[i][r] + add + rv[i][r]) * o_scale);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row0 + r < o_rows) stg1(gp + (row0 + r) * o_Cout, (acc[i][r] + add + rv[i][r]) * o_scale);
+                }
             }
         }
     }
