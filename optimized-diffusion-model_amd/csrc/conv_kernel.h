@@ -58,7 +58,7 @@ struct ConvArgs {
     float out_scale, eps;
     int S, BN, Mpad;
     float drop_p; uint64_t drop_seed; uint32_t op_id;   // train mode: dropout after GN+SiLU (Dropout_0, RD/models/layerspp.py:204)
-    int dbg;                      // ablation switches for profiling builds (0 in production): 1 = skip GEMM, 2 = skip GN
+    int dbg;                      // unused (kept so the argument block layout of recorded launches stays stable)
 };
 
 __host__ __device__ inline size_t conv_lds_bytes(const ConvArgs& a) {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
         // ---- conv phases: flattened step q = tap * nch + chunk; B for step q sits at wpk + q * bstride
         {
             const int nch = a.Cv >> 4;
-            const int nsteps = (a.dbg & 1) ? 0 : a.ntap * nch;
+            const int nsteps = a.ntap * nch;
             const size_t bstride = (size_t)a.Cout_pad * 16;
             const float* Wl = a.wpk + (size_t)(colbase + lrow) * 16 + kq * 4;
             f32x4 bring[PF][NT];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
     for (int i = tid; i < a.Mpad * tw; i += RDMI_THREADS) tabL[i] = a.tab[i];
 
     // ---- stage 2: GroupNorm statistics (two-pass, in LDS) + affine + SiLU, in place
-    if (a.G > 0 && !(a.dbg & 2)) {
+    if (a.G > 0) {
         __syncthreads();
         const int G = a.G, Cg = a.Cv / G;
         const int pairs = a.S * G;                 // power of two, <= 256 (host-checked)

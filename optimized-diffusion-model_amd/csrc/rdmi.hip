@@ -335,7 +335,6 @@ struct Builder {
         a.G = s.gn.empty() ? 0 : std::min(Cin / 4, 32);
         a.Cout = s.Cout; a.Cout_pad = pad16(s.Cout);
         a.out_scale = s.scale; a.eps = 1e-6f;
-        if (const char* e = std::getenv("RDMI_DBG")) a.dbg = atoi(e);
         a.dense_stride = c->dense_total; a.dense_off = s.dense_off < 0 ? 0 : s.dense_off;
         a.CscA = s.CscA; a.CscB = s.CscB; a.Csc = pad16(s.CscA + s.CscB) * ((s.CscA + s.CscB) > 0);
         a.HWsa = s.Hsa * s.Wsa;
@@ -350,7 +349,6 @@ struct Builder {
         else if (a.HWo >= 40) { op.cfg = 0; a.S = 1; a.BN = 64; }                  // <1,4,1,6,1>
         else if (a.HWo >= 9) { op.cfg = 1; a.S = std::max(1, 64 / a.HWo); a.BN = 32; }   // <2,2,1,3,1>
         else { op.cfg = 2; a.S = std::max(1, 16 / a.HWo); a.BN = 32; }             // <1,2,2,1,1>
-        if (const char* e = std::getenv("RDMI_CONV9_BN32")) if (atoi(e) && op.cfg == 0) { op.cfg = 1; a.BN = 32; }
         a.Mpad = pad16(a.S * a.HWo);
         const int cap[4] = {96, 96, 16, 128};
         if (a.Mpad > cap[op.cfg] || a.Cout_pad % a.BN != 0 || (op.cfg == 2 && (a.Cv >> 4) < 2)) { *err = fail("conv %s: unsupported tile (HWo=%d Cout=%d)", s.name.c_str(), a.HWo, a.Cout); return -1; }
