@@ -57,6 +57,8 @@ struct LinArgs {
     float* Y; int ldy;
     int M, N, K;
     int pre;
+    // pre == 1: X -> SiLU(X);  pre == 3: X row (ldx may be 0: one row shared by all samples) + label embedding -> SiLU
+    //           (the sampler's precomputed time-MLP row, see rdmi_pc_sample);
     // pre == 2: X = sigma (or sde-time t when t_is_time) of sample (row % x_mod)
     const float* fourW; int nfour; int x_mod; int t_is_time; float smin, ratio;
     int use_scalar; float t_scalar;                 // X == null: every row uses this one time (the PC loop, RD/sampling.py:329)
@@ -70,16 +72,29 @@ __device__ __forceinline__ float sigma_of(float v, int t_is_time, float smin, fl
     return t_is_time ? smin * powf(ratio, v) : v;
 }
 
+// NT column tiles per wave (the workgroup covers 64*NT columns): the A fragment -- which may carry a Fourier / SiLU / label
+// prologue -- is formed once per k-chunk and reused NT times.
+template <int NT, int UNR = 4>
 __global__ __launch_bounds__(RDMI_THREADS) void linear_mfma_kernel(LinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kq = lane >> 4;
     const int row = blockIdx.x * 16 + lrow;
-    const int col = blockIdx.y * 64 + wave * 16 + lrow;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int col[NT], lcol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        col[t] = blockIdx.y * (64 * NT) + (wave * NT + t) * 16 + lrow;
+        lcol[t] = min(col[t], a.Npad - 16 + lrow);           // tiles past the padded width re-read the last one (never stored)
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ls = 0.f;
     if (a.pre == 2 && row < a.M) ls = logf(sigma_of(a.use_scalar ? a.t_scalar : a.X[row % a.x_mod], a.t_is_time, a.smin, a.ratio));
+#pragma unroll UNR
     for (int ch = 0; ch < (a.K >> 4); ++ch) {
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(a.W + ((size_t)ch * a.Npad + col) * 16 + kq * 4);
+        f32x4 bf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const f32x4*>(a.W + ((size_t)ch * a.Npad + lcol[t]) * 16 + kq * 4);
         f32x4 af = {0.f, 0.f, 0.f, 0.f};
         if (row < a.M) {
             const int k0 = ch * 16 + kq * 4;
@@ -92,23 +107,30 @@ __global__ __launch_bounds__(RDMI_THREADS) void linear_mfma_kernel(LinArgs a) {
                 }
             } else {
                 af = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + k0);
-                if (a.pre == 1)
+                if (a.pre == 3 && a.labels && row < a.label_rows)      // same order of additions as the time_mlp.2 epilogue below
+                    for (int j = 0; j < 4; ++j)
+                        for (int c = 0; c < a.ncls; ++c) af[j] += a.labels[(size_t)row * a.ncls + c] * a.Wl[(size_t)(k0 + j) * a.ncls + c];
+                if (a.pre == 1 || a.pre == 3)
                     for (int j = 0; j < 4; ++j) af[j] = silu_f(af[j]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = mfma16(af[j], bf[j], acc);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(af[j], bf[t][j], acc[t]);
     }
-    if (col < a.N) {
-        float add = a.bias ? a.bias[col] : 0.f;
-        if (a.labels) add += a.bl[col];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (col[t] >= a.N) continue;
+        float add = a.bias ? a.bias[col[t]] : 0.f;
+        if (a.bl && a.pre != 3) add += a.bl[col[t]];
         for (int r = 0; r < 4; ++r) {
             const int orow = blockIdx.x * 16 + kq * 4 + r;
             if (orow >= a.M) continue;
-            float v = acc[r] + add;
-            if (a.labels && orow < a.label_rows)
-                for (int c = 0; c < a.ncls; ++c) v += a.labels[(size_t)orow * a.ncls + c] * a.Wl[(size_t)col * a.ncls + c];
-            a.Y[(size_t)orow * a.ldy + col] = v;
+            float v = acc[t][r] + add;
+            if (a.labels && a.pre != 3 && orow < a.label_rows)
+                for (int c = 0; c < a.ncls; ++c) v += a.labels[(size_t)orow * a.ncls + c] * a.Wl[(size_t)col[t] * a.ncls + c];
+            a.Y[(size_t)orow * a.ldy + col[t]] = v;
         }
     }
 }

@@ -132,6 +132,7 @@ struct rdmi_ctx {
     float *d_h1 = nullptr, *d_temb = nullptr, *d_dense = nullptr;
     // sampler scratch
     float *d_s2 = nullptr, *d_score = nullptr, *d_z = nullptr, *d_norms = nullptr, *d_ts = nullptr, *d_tvec = nullptr;
+    float *d_tt = nullptr, *d_th1 = nullptr; int tt_cap = 0;   // sampler: time-path rows of all updates (rdmi_pc_sample)
     int ts_cap = 0;
     StepState* d_state = nullptr;
     // fused (workgroup-resident) path
@@ -1175,6 +1176,7 @@ struct FwdIn {
     int t_is_time; float smin, ratio;
     const float* labels; int label_rows;
     float* out; int NB;
+    const float* tt_row = nullptr;        // sampler: precomputed time_mlp.2 output row (+ both biases) of this evaluation's t
 };
 
 int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
@@ -1184,6 +1186,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     if (a.conditional && !f.labels) return fail("class_labels is required: the model is conditional (label_emb) -- reference raises here too (RD/models/ncsnpp.py:262)");
     const int T = c->temb, Np_t = (T + 63) & ~63, Np_d = (c->dense_total + 63) & ~63;
     // ---- embedding: Fourier -> Linear -> SiLU -> Linear (+label_emb) -> [SiLU -> all Dense_0]
+    if (!f.tt_row) {
     LinArgs l{};
     l.M = f.NB; l.fourW = P(c, "time_embed.W"); l.nfour = a.nf;
     l.X = f.sig; l.x_mod = f.sig_mod > 0 ? f.sig_mod : f.NB; l.t_is_time = f.t_is_time; l.smin = f.smin; l.ratio = f.ratio;
@@ -1192,7 +1195,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     l.Y = c->d_h1; l.ldy = T;
     {
         ProfScope ps(c, s, "linear_mfma(time_mlp.0)", 2.0 * f.NB * T * 2 * a.nf);
-        hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l);
+        hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l);
     }
     LinArgs l2{};
     l2.M = f.NB; l2.X = c->d_h1; l2.ldx = T; l2.pre = 1; l2.K = T; l2.W = c->d_w + c->w_t2; l2.Npad = Np_t; l2.N = T;
@@ -1200,14 +1203,19 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     if (a.conditional) { l2.labels = f.labels; l2.Wl = P(c, "label_emb.weight"); l2.bl = P(c, "label_emb.bias"); l2.ncls = a.num_classes; l2.label_rows = f.label_rows; }
     {
         ProfScope ps(c, s, "linear_mfma(time_mlp.2)", 2.0 * f.NB * T * T);
-        hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l2);
+        hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l2);
+    }
     }
     LinArgs l3{};
-    l3.M = f.NB; l3.X = c->d_temb; l3.ldx = T; l3.pre = 1; l3.K = T; l3.W = c->d_w + c->w_dense; l3.Npad = Np_d; l3.N = c->dense_total;
+    l3.M = f.NB; l3.X = c->d_temb; l3.ldx = T; l3.pre = 1; l3.K = T;
+    if (f.tt_row) {     // every sample shares the time row; the label embedding is added in the prologue (same sums as time_mlp.2's epilogue)
+        l3.X = f.tt_row; l3.ldx = 0; l3.pre = 3;
+        if (a.conditional) { l3.labels = f.labels; l3.Wl = P(c, "label_emb.weight"); l3.ncls = a.num_classes; l3.label_rows = f.label_rows; }
+    } l3.W = c->d_w + c->w_dense; l3.Npad = Np_d; l3.N = c->dense_total;
     l3.bias = c->d_w + c->b_dense; l3.Y = c->d_dense; l3.ldy = c->dense_total;
     {
         ProfScope ps(c, s, "linear_mfma(Dense_0 x all)", 2.0 * f.NB * T * c->dense_total);
-        hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_d / 64)), dim3(RDMI_THREADS), 0, s, l3);
+        hipLaunchKernelGGL((linear_mfma_kernel<1, 16>), dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_d / 64)), dim3(RDMI_THREADS), 0, s, l3);
     }
     HIP_OK(hipGetLastError());
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
@@ -1312,7 +1320,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         train_registry().erase(c);
         delete T;
     }
-    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state};
+    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete c;
@@ -1507,9 +1515,38 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
         for (int i = 0; i < o->N; ++i)
             ts[(size_t)i] = (float)(i < o->N / 2 ? (double)start + step * i : (double)end - step * (o->N - 1 - i));
     }
-    // one score evaluation at the shared time t: the raw network output lands in d_s2 ([2B] with CFG, [B] without)
-    auto net_eval = [&](float t) -> int {
+    // The time path of the embedding (Fourier -> time_mlp.0 -> SiLU -> time_mlp.2, + both biases) depends only on the
+    // update's t, which is known up front: evaluate it for ALL updates in two launches (one row per update) instead of two
+    // launches per score evaluation; per evaluation only the batched Dense_0 GEMM remains, which adds the label embedding
+    // to the shared row in its prologue.
+    const int nupd = o->N - 1, T = c->temb, Np_t = (T + 63) & ~63;
+    if (c->tt_cap < nupd) {
+        if (c->d_tt) { HIP_OK(hipFree(c->d_tt)); HIP_OK(hipFree(c->d_th1)); HIP_OK(hipFree(c->d_ts)); c->d_tt = c->d_th1 = c->d_ts = nullptr; c->tt_cap = 0; }
+        HIP_OK(hipMalloc((void**)&c->d_tt, (size_t)pad16(nupd) * T * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_th1, (size_t)pad16(nupd) * T * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_ts, (size_t)pad16(nupd) * sizeof(float)));
+        c->tt_cap = nupd;
+    }
+    {
+        HIP_OK(hipMemcpyAsync(c->d_ts, ts.data(), (size_t)nupd * sizeof(float), hipMemcpyHostToDevice, s));
+        const rdmi_arch& a = c->arch;
+        LinArgs l{};
+        l.M = nupd; l.fourW = P(c, "time_embed.W"); l.nfour = a.nf; l.X = c->d_ts; l.x_mod = nupd; l.t_is_time = 1; l.smin = smin; l.ratio = ratio;
+        l.pre = 2; l.K = pad16(2 * a.nf); l.W = c->d_w + c->w_t0; l.Npad = Np_t; l.N = T; l.bias = P(c, "time_mlp.0.bias"); l.Y = c->d_th1; l.ldy = T;
+        LinArgs l2{};
+        l2.M = nupd; l2.X = c->d_th1; l2.ldx = T; l2.pre = 1; l2.K = T; l2.W = c->d_w + c->w_t2; l2.Npad = Np_t; l2.N = T;
+        l2.bias = P(c, "time_mlp.2.bias"); l2.Y = c->d_tt; l2.ldy = T;
+        if (a.conditional) l2.bl = P(c, "label_emb.bias");
+        ProfScope ps(c, s, "linear_mfma(time path, all updates)", 2.0 * nupd * T * (2 * a.nf + T));
+        hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(nupd, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l);
+        hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(nupd, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l2);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(s));      // ts (host vector) must outlive the copy; once per sampling call
+    }
+    // one score evaluation at update i's shared time: the raw network output lands in d_s2 ([2B] with CFG, [B] without)
+    auto net_eval = [&](int i, float t) -> int {
         FwdIn f{x, o->use_cfg ? B : 0, nullptr, 0, t, 1, smin, ratio, labels, B, c->d_s2, NBm};
+        f.tt_row = c->d_tt + (size_t)i * T;
         return run_forward(c, f, s);
     };
     uint32_t draw = 0;
@@ -1517,7 +1554,7 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
         const float t = ts[(size_t)i];
         if (o->corrector == 1) {
             for (int k = 0; k < o->n_steps_each; ++k, ++draw) {
-                if (int e = net_eval(t)) return e;
+                if (int e = net_eval(i, t)) return e;
                 ProfScope ps(c, s, "langevin_update", 0);
                 hipLaunchKernelGGL(langevin_prep_kernel, dim3((unsigned)B), dim3(64), 0, s, (const float*)c->d_s2, weight,
                                    noise ? noise + (size_t)draw * BE : (const float*)nullptr, c->d_score, c->d_z, c->d_norms, B, E,
@@ -1527,7 +1564,7 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
                                    (float*)nullptr, B, E, o->snr, 0);
             }
         }
-        if (int e = net_eval(t)) return e;
+        if (int e = net_eval(i, t)) return e;
         {
             ProfScope ps(c, s, "em_fused", 0);
             hipLaunchKernelGGL(em_fused_kernel, dim3(gBE), dim3(RDMI_THREADS), 0, s, (const float*)x, (const float*)c->d_s2, weight,
