@@ -53,16 +53,24 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # Rehearsal on a box with fewer GPUs than ranks (never what the driver runs): RDMI_BENCH_BACKEND=gloo puts every rank
+    # on cuda:(local % device_count) and exchanges through gloo, to exercise this file's N>1 control flow.
+    backend = os.environ.get('RDMI_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 under torch.distributed.run')
     torch.cuda.set_device(local)
     dev = torch.device(f'cuda:{local}')
 
     import __graft_entry__ as ge
-    if local == 0:
+    if int(os.environ.get('LOCAL_RANK', '0')) == 0:
         ge.build()                    # one rank per node compiles (no-op when librdmi.so is fresh) ...
     if world > 1:
         dist.barrier()
