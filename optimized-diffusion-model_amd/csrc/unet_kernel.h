@@ -268,7 +268,7 @@ __device__ __forceinline__ int arow(const short* tab, int m, int lds_off, int rs
 //    rows are the zero row, so there is no tail code (instruction-cache footprint matters: the whole interpreter
 //    must stay resident in the 64 KiB I-cache or every op transition refetches cold code);
 //  * A fragments are read from LDS one step ahead of the MFMAs that consume them.
-template <int NMT, int PF, bool M4 = false>
+template <int NMT, int PF, bool M4 = false, bool LM4 = false>
 __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int n, int mt0, int WM, int nt, int lane, long long* fine) {
     const int lrow = lane & 15, kq = lane >> 4;
     if (fine) fine[0] = clock64();
@@ -290,7 +290,8 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
     for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int mrow[NMT];
 #pragma unroll
-    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + (M4 ? (lane & 3) : lrow);     // M4: images of <= 4 pixels
+    for (int i = 0; i < NMT; ++i)      // M4: images of <= 4 pixels; LM4: the LAST row tile has <= 4 real rows (81 = 5 x 16 + 1)
+        mrow[i] = (mt0 + i * WM) * 16 + ((M4 || (LM4 && i == NMT - 1)) ? (lane & 3) : lrow);
     // epilogue operands are fetched now so their global latency hides under the GEMM
     float add = 0.f;
     if (col < o_Cout) {
@@ -354,20 +355,22 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < NMT; ++i) acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                        for (int i = 0; i < NMT; ++i)
+                            acc[i] = (LM4 && i == NMT - 1) ? mfma4(af[i][j], ring[p][j], acc[i]) : mfma16(af[i][j], ring[p][j], acc[i]);
                 }
                 ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nsteps - 1) * bstride);
             }
         }
     }
     if (NMT == 1) acc[0] += acc2;
-    if (M4) {               // sum the four k groups: afterwards every lane holds D[row r][col lrow], the kq == 0 lanes' share
-#pragma unroll              // of the 16x16x4 result layout, so the epilogue below is unchanged (other lanes' rows are >= 4)
+    if (M4 || LM4) {        // sum the four k groups: afterwards every lane holds D[row r][col lrow], the kq == 0 lanes' share
+        constexpr int ti = M4 ? 0 : NMT - 1;   // of the 16x16x4 result layout, so the epilogue below is unchanged (other lanes' rows are >= 4)
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = acc[0][r];
+            float v = acc[ti][r];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            acc[0][r] = v;
+            acc[ti][r] = v;
         }
     }
     if (fine) fine[4] = clock64();
@@ -473,7 +476,14 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
                     else fconv_wave<1, 8>(w, u, n, mt0, WM, nt, lane, fine);
                     break;
                 case 2: fconv_wave<2, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
-                case 3: fconv_wave<3, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 3: {
+                    // 81 rows = 5 full tiles + 1 row: the wave that owns the nearly empty last tile runs it on the 4x4x1 form
+                    // (13 instead of 32 MFMA cycles per step); it shares its SIMD with a wave of full tiles, so the pipe time saved is real
+                    const int last_rows = OPI(w, rows) - (mt0 + 2 * WM) * 16;
+                    if (last_rows >= 1 && last_rows <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<3, 4, false, true>(w, u, n, mt0, WM, nt, lane, fine);
+                    else fconv_wave<3, 4>(w, u, n, mt0, WM, nt, lane, fine);
+                    break;
+                }
                 case 4: fconv_wave<4, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
                 default: break;
             }
