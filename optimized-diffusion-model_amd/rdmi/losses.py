@@ -83,7 +83,10 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, likelihood_weig
             optimizer = state['optimizer']
             optimizer.zero_grad()
             loss = loss_fn(model, batch, class_labels=class_labels)
-            loss.backward()
+            if state['scaler'] is None:
+                loss.backward()
+            else:                                   # RD/losses.py:143-146 (the HIP backward is linear in the incoming gradient)
+                state['scaler'].scale(loss).backward()
             optimize_fn(optimizer, model.parameters(), step=state['step'], scaler=state['scaler'])
             state['step'] += 1
             state['ema'].update(model.parameters())
