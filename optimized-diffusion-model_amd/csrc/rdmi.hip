@@ -1221,13 +1221,18 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
     if (c->fused_ok && c->use_fused && !c->debug_taps) {
         static bool attr_set = false;
-        if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        if (!attr_set) {
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
         UnetArgs ua = c->fargs;
         ua.x_in = f.x; ua.x_mod = f.x_mod; ua.out = f.out; ua.NB = f.NB;
         double fl = 0;
         for (auto& op : c->ops) fl += op.flops_per_sample;
         ProfScope ps(c, s, "unet_wg_kernel", fl * f.NB);
-        hipLaunchKernelGGL(unet_wg_kernel, dim3((unsigned)f.NB), dim3(UW_THREADS), c->fused_lds, s, ua);
+        if (ua.stamps || ua.dbg) hipLaunchKernelGGL(unet_wg_kernel<true>, dim3((unsigned)f.NB), dim3(UW_THREADS), c->fused_lds, s, ua);   // diagnostic build
+        else hipLaunchKernelGGL(unet_wg_kernel<false>, dim3((unsigned)f.NB), dim3(UW_THREADS), c->fused_lds, s, ua);
         HIP_OK(hipGetLastError());
         return 0;
     }

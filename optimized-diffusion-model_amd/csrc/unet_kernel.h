@@ -268,10 +268,10 @@ __device__ __forceinline__ int arow(const short* tab, int m, int lds_off, int rs
 //    rows are the zero row, so there is no tail code (instruction-cache footprint matters: the whole interpreter
 //    must stay resident in the 64 KiB I-cache or every op transition refetches cold code);
 //  * A fragments are read from LDS one step ahead of the MFMAs that consume them.
-template <int NMT, int PF, bool M4 = false, bool LM4 = false>
+template <bool DIAG, int NMT, int PF, bool M4 = false, bool LM4 = false>
 __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int n, int mt0, int WM, int nt, int lane, long long* fine) {
     const int lrow = lane & 15, kq = lane >> 4;
-    if (fine) fine[0] = clock64();
+    if (DIAG && fine) fine[0] = clock64();
     // every op field this wave needs, pinned to scalar registers up front (the descriptor lives in LDS)
     const int o_rows = OPI(w, rows), o_Cout = OPI(w, Cout), o_Cout_pad = OPI(w, Cout_pad), o_ntap = OPI(w, ntap);
     const int o_dense = OPI(w, dense_off), o_resid = OPI(w, resid_off), o_resid_rs = OPI(w, resid_rs);
@@ -320,7 +320,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
         f32x4 afn[NMT];
 #pragma unroll
         for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i]);
-        if (fine) fine[1] = clock64();
+        if (DIAG && fine) fine[1] = clock64();
         for (int q = 0; q < npad; q += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
@@ -373,7 +373,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
             acc[ti][r] = v;
         }
     }
-    if (fine) fine[4] = clock64();
+    if (DIAG && fine) fine[4] = clock64();
     // ---- epilogue: three destinations, each its own (wave-uniform) branch so LDS stores stay ds_write and global
     //      stores stay global_store (a merged pointer would degrade both to flat_store)
     if (o_kind == 3) {                        // fused q/k/v projection: the column tile decides the destination
@@ -458,9 +458,10 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
             }
         }
     }
-    if (fine) fine[5] = clock64();
+    if (DIAG && fine) fine[5] = clock64();
 }
 
+template <bool DIAG>
 __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n, int wave, int lane, long long* fine) {
     const int ntiles = OPI(w, Cout_pad) >> 4, mtiles = OPI(w, mtiles);
     const int lWN = (ntiles >= 8 && (ntiles & 7) == 0) ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // log2 of waves along N
@@ -472,19 +473,19 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
             const int left = (mtiles - mt0 + WM - 1) >> lWM;
             switch (left >= 4 ? 4 : left) {
                 case 1:
-                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<1, 8, true>(w, u, n, mt0, WM, nt, lane, fine);
-                    else fconv_wave<1, 8>(w, u, n, mt0, WM, nt, lane, fine);
+                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<DIAG, 1, 8, true>(w, u, n, mt0, WM, nt, lane, fine);
+                    else fconv_wave<DIAG, 1, 8>(w, u, n, mt0, WM, nt, lane, fine);
                     break;
-                case 2: fconv_wave<2, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 2: fconv_wave<DIAG, 2, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
                 case 3: {
                     // 81 rows = 5 full tiles + 1 row: the wave that owns the nearly empty last tile runs it on the 4x4x1 form
                     // (13 instead of 32 MFMA cycles per step); it shares its SIMD with a wave of full tiles, so the pipe time saved is real
                     const int last_rows = OPI(w, rows) - (mt0 + 2 * WM) * 16;
-                    if (last_rows >= 1 && last_rows <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<3, 4, false, true>(w, u, n, mt0, WM, nt, lane, fine);
-                    else fconv_wave<3, 4>(w, u, n, mt0, WM, nt, lane, fine);
+                    if (last_rows >= 1 && last_rows <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<DIAG, 3, 4, false, true>(w, u, n, mt0, WM, nt, lane, fine);
+                    else fconv_wave<DIAG, 3, 4>(w, u, n, mt0, WM, nt, lane, fine);
                     break;
                 }
-                case 4: fconv_wave<4, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
+                case 4: fconv_wave<DIAG, 4, 4>(w, u, n, mt0, WM, nt, lane, fine); break;
                 default: break;
             }
         }
@@ -583,6 +584,9 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
     }
 }
 
+// DIAG = true is the diagnostic build of the same kernel (per-op cycle stamps, per-op-kind ablation); the production
+// instantiation compiles all of that away -- the interpreter has to stay inside the 64 KiB instruction cache.
+template <bool DIAG>
 __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         for (int i = tid; i < (u.zero_bytes >> 2); i += UW_THREADS) z[i] = 0.f;
     }
     float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
-    if (u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
+    if (DIAG && u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
     // descriptors are kept TWO ops ahead (cur, nxt resident; the load for pc+2 is in flight) so that small operands
     // of the next op can be prefetched while the current one runs
     OpW cur = opw_load(u.prog, lane);
@@ -606,23 +610,23 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     gn_prefetch(cur, tid, pgm, pbt);
     for (int pc = 0; pc < u.nops; ++pc) {
         const OpW nn = opw_load(u.prog + (pc + 2 < u.nops ? pc + 2 : u.nops - 1), lane);
-        long long* fine = (u.stamps && n == 0 && tid == 0) ? u.stamps + 1024 + pc * 8 : nullptr;
+        long long* fine = (DIAG && u.stamps && n == 0 && tid == 0) ? u.stamps + 1024 + pc * 8 : nullptr;
         const int kind = OPI(cur, kind);
-        if (fine) fine[2] = clock64();
+        if (DIAG && fine) fine[2] = clock64();
         f32x4 ngm = pgm, nbt = pbt;
         if (pc + 1 < u.nops) gn_prefetch(nxt, tid, ngm, nbt);
-        if (fine) fine[3] = clock64();
-        const int skip = u.dbg ? ((kind == FOP_GN ? 4 : kind == FOP_CONV ? 8 : kind == FOP_ATTN ? 16 : 32) & u.dbg) : 0;
+        if (DIAG && fine) fine[3] = clock64();
+        const int skip = (DIAG && u.dbg) ? ((kind == FOP_GN ? 4 : kind == FOP_CONV ? 8 : kind == FOP_ATTN ? 16 : 32) & u.dbg) : 0;
         switch (skip ? -1 : kind) {
             case FOP_GATHER: fop_gather(cur, u, n, tid); break;
             case FOP_STORE: fop_store(cur, n, tid); break;
-            case FOP_GN: fop_gn(cur, stat, tid, pgm, pbt, u.dbg); break;
-            case FOP_CONV: fop_conv(cur, u, n, wave, lane, fine); break;
+            case FOP_GN: fop_gn(cur, stat, tid, pgm, pbt, DIAG ? u.dbg : 0); break;
+            case FOP_CONV: fop_conv<DIAG>(cur, u, n, wave, lane, fine); break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             default: break;
         }
         __syncthreads();
-        if (u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
+        if (DIAG && u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
         cur = nxt; nxt = nn; pgm = ngm; pbt = nbt;
     }
 }
