@@ -473,8 +473,8 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
             const int left = (mtiles - mt0 + WM - 1) >> lWM;
             switch (left >= 4 ? 4 : left) {
                 case 1:
-                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<DIAG, 1, 8, true>(w, u, n, mt0, WM, nt, lane, fine);
-                    else fconv_wave<DIAG, 1, 8>(w, u, n, mt0, WM, nt, lane, fine);
+                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_wave<DIAG, 1, 4, true>(w, u, n, mt0, WM, nt, lane, fine);
+                    else fconv_wave<DIAG, 1, 4>(w, u, n, mt0, WM, nt, lane, fine);
                     break;
                 case 2: fconv_wave<DIAG, 2, 8>(w, u, n, mt0, WM, nt, lane, fine); break;
                 case 3: {
