@@ -33,7 +33,7 @@ PEAK_HBM_GBPS = 8000.0
 GFLOP_PER_FORWARD = 0.220438528        # 110 219 264 MAC per sample-forward at 9x9
 ACT_BYTES_PER_FORWARD = 4440464        # layer-granular activation bytes per sample-forward
 WEIGHT_BYTES = 25019652
-PMC_TRAFFIC_BYTES_UNET_B128 = (2 * 98248 + 15576) * 1024   # profiles/r01_pmc_hbm_traffic_unet_wg_kernel.md
+PMC_TRAFFIC_BYTES_UNET_B128 = (2 * 98287 + 15576) * 1024   # profiles/r01_pmc_hbm_traffic_unet_wg_kernel.md
 
 
 def main():
