@@ -71,7 +71,8 @@ struct UnetArgs {
     float* out;                                   // network output [NB][HW][channels]   (CONV dst_kind 2, g_out null)
     int NB;
     int dbg;                                      // diagnostic ablations (0 in production; results are wrong when set): bit 2 skips GN
-                                                  // bodies, bit 3 CONV, bit 4 ATTN, bit 5 GATHER/STORE (scripts/gpu_ablate.py)
+                                                  // bodies, bit 3 CONV, bit 4 ATTN, bit 5 GATHER/STORE, bits 6/7 GN statistics / apply,
+                                                  // bit 8 conv epilogues, bit 9 conv main loops (scripts/gpu_ablate.py)
     long long* stamps;                            // diagnostic: per-op shader-clock stamps of workgroup 0 (null in production)
 };
 
@@ -301,7 +302,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
     }
     {
         const int nsteps = o_ntap * nch;
-        const int npad = ((nsteps + PF - 1) / PF) * PF;
+        const int npad = (DIAG && (u.dbg & 512)) ? 0 : ((nsteps + PF - 1) / PF) * PF;     // ablation: no main loop
         const size_t bstride = (size_t)o_Cout_pad * 16;
         const float* Wl = m_w + (size_t)col * 16 + kq * 4;
         f32x4 ring[PF];
@@ -374,6 +375,7 @@ __device__ __forceinline__ void fconv_wave(const OpW& w, const UnetArgs& u, int 
         }
     }
     if (DIAG && fine) fine[4] = clock64();
+    if (DIAG && (u.dbg & 256)) return;                 // ablation: no epilogue
     // ---- epilogue: three destinations, each its own (wave-uniform) branch so LDS stores stay ds_write and global
     //      stores stay global_store (a merged pointer would degrade both to flat_store)
     if (o_kind == 3) {                        // fused q/k/v projection: the column tile decides the destination
