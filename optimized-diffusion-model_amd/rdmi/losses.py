@@ -22,33 +22,39 @@ from . import _native
 from .models import utils as mutils
 
 
+_OPTIMIZERS = {'Adam': optim.Adam, 'AdamW': optim.AdamW}
+
+
 def get_optimizer(config, params):
-    """RD/losses.py:12-23."""
+    """RD/losses.py:12-23: Adam / AdamW from config.optim.{lr, beta1, beta2, eps, weight_decay}."""
     o = config.optim
-    if o.optimizer == 'Adam':
-        return optim.Adam(params, lr=o.lr, betas=(o.beta1, o.beta2), eps=o.eps, weight_decay=o.weight_decay)
-    if o.optimizer == 'AdamW':
-        return optim.AdamW(params, lr=o.lr, betas=(o.beta1, o.beta2), eps=o.eps, weight_decay=o.weight_decay)
-    raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
+    cls = _OPTIMIZERS.get(o.optimizer)
+    if cls is None:
+        raise NotImplementedError(f'Optimizer {o.optimizer} not supported yet!')
+    return cls(params, lr=o.lr, betas=(o.beta1, o.beta2), eps=o.eps, weight_decay=o.weight_decay)
 
 
 def optimization_manager(config):
-    """RD/losses.py:26-49: linear warm-up, gradient clipping (disabled if negative), optional GradScaler."""
+    """RD/losses.py:26-49.  Returns optimize_fn(optimizer, params, step, lr, warmup, grad_clip, scaler): linear learning-rate
+    warm-up over `warmup` steps, global-norm clipping at `grad_clip` (negative: off), then the optimizer step -- through the
+    GradScaler when one is given (its unscale_ comes first so the clip sees true gradients)."""
+    oc = config.optim
 
-    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup,
-                    grad_clip=config.optim.grad_clip, scaler=None):
-        if scaler is not None:
+    def optimize_fn(optimizer, params, step, lr=oc.lr, warmup=oc.warmup, grad_clip=oc.grad_clip, scaler=None):
+        scaled = scaler is not None
+        if scaled:
             scaler.unscale_(optimizer)
         if warmup > 0:
-            for g in optimizer.param_groups:
-                g['lr'] = lr * np.minimum(step / warmup, 1.0)
+            ramp = lr * np.minimum(step / warmup, 1.0)
+            for group in optimizer.param_groups:
+                group['lr'] = ramp
         if grad_clip >= 0:
             torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
-        if scaler is None:
-            optimizer.step()
-        else:
+        if scaled:
             scaler.step(optimizer)
             scaler.update()
+        else:
+            optimizer.step()
 
     return optimize_fn
 

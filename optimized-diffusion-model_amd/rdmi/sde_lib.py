@@ -1,90 +1,89 @@
-"""SDE classes: abstract SDE, its reverse, and the reflected variance-exploding SDE.
+"""Schedules of the reflected variance-exploding SDE and the reverse-time wrapper (host side).
 
-Host mirror of Reflected-Diffusion/sde_lib.py ("RD/sde_lib.py").  These are scalar-per-sample schedule
-formulas ([B] tensors); the per-element sampler updates that consume them run in librdmi
-(rdmi_em_update / rdmi_pc_sample evaluate sigma(t), g(t) in-kernel with the same fp32 operation order).
+API counterpart of Reflected-Diffusion/sde_lib.py ("RD/sde_lib.py"): `SDE` (abstract), `SDE.reverse(score_fn,
+probability_flow)` and `RVESDE`.  Everything here is a per-sample scalar schedule ([B] tensors); the per-element
+sampler arithmetic that consumes sigma(t) and g(t) runs in librdmi (rdmi_em_update / rdmi_pc_sample evaluate them
+in-kernel with the same fp32 operation order).
 """
 import abc
+import math
 
-import numpy as np
 import torch
 
 
+def _bcast(v):
+    """[B] -> [B,1,1,1] so that per-sample scalars multiply image-shaped tensors."""
+    return v[:, None, None, None]
+
+
 class SDE(abc.ABC):
-    """RD/sde_lib.py:7-111."""
+    """Interface of RD/sde_lib.py:7-111: N discretisation steps, horizon T, forward coefficients, marginals, prior."""
 
     def __init__(self, N):
         super().__init__()
         self.N = N
 
+    # -- what a concrete SDE supplies ------------------------------------------------------------------------------
     @property
     @abc.abstractmethod
-    def T(self):
-        """End time of the SDE."""
+    def T(self): ...
 
     @abc.abstractmethod
     def sde(self, x, t):
-        """(drift, diffusion) at (x, t)."""
+        """-> (drift like x, diffusion [B])"""
 
     @abc.abstractmethod
     def marginal_prob(self, x, t):
-        """(mean, std) of p_t(x | x_0)."""
+        """-> (mean like x, std [B]) of the perturbation kernel p_t(x | x_0)"""
 
     @abc.abstractmethod
-    def prior_sampling(self, shape):
-        """One draw from p_T."""
+    def prior_sampling(self, shape): ...
 
     @abc.abstractmethod
-    def prior_logp(self, z):
-        """log p_T(z)."""
+    def prior_logp(self, z): ...
 
+    # -- derived ---------------------------------------------------------------------------------------------------
     def discretize(self, x, t):
-        """Euler-Maruyama discretisation x_{i+1} = x_i + f + G z (RD/sde_lib.py:53-69)."""
-        dt = 1 / self.N
-        drift, diffusion = self.sde(x, t)
-        return drift * dt, diffusion * torch.sqrt(torch.tensor(dt, device=t.device))
+        """One Euler-Maruyama step's (f, G) with step 1/N (RD/sde_lib.py:53-69)."""
+        h = 1 / self.N
+        f, g = self.sde(x, t)
+        return f * h, g * torch.sqrt(torch.tensor(h, device=t.device))
 
     def reverse(self, score_fn, probability_flow=False):
-        """Reverse-time SDE / probability-flow ODE (RD/sde_lib.py:71-111)."""
-        N, T = self.N, self.T
-        fwd_sde, fwd_disc = self.sde, self.discretize
+        """Reverse-time SDE, or the probability-flow ODE when `probability_flow` (RD/sde_lib.py:71-111).  As in the
+        reference the result is an instance of a subclass of type(self) (so isinstance checks on the forward type hold),
+        carrying N, T and `probability_flow`; only `sde` and `discretize` are overridden."""
+        forward = self
+        half = 0.5 if probability_flow else 1.0
 
-        class RSDE(self.__class__):
-            def __init__(self):
-                self.N = N
-                self.probability_flow = probability_flow
+        def _reverse_coeffs(f, g, x, t):
+            f = f - _bcast(g) ** 2 * score_fn(x, t) * half
+            return f, (torch.zeros_like(g) if probability_flow else g)
 
-            @property
-            def T(self):
-                return T
+        def _init(rs):
+            rs.N = forward.N
+            rs.probability_flow = probability_flow
 
-            def sde(self, x, t):
-                drift, diffusion = fwd_sde(x, t)
-                score = score_fn(x, t)
-                drift = drift - diffusion[:, None, None, None] ** 2 * score * (0.5 if self.probability_flow else 1.)
-                diffusion = torch.zeros_like(diffusion) if self.probability_flow else diffusion
-                return drift, diffusion
-
-            def discretize(self, x, t):
-                f, G = fwd_disc(x, t)
-                rev_f = f - G[:, None, None, None] ** 2 * score_fn(x, t) * (0.5 if self.probability_flow else 1.)
-                rev_G = torch.zeros_like(G) if self.probability_flow else G
-                return rev_f, rev_G
-
-        return RSDE()
+        members = {
+            '__init__': _init,
+            'T': property(lambda rs: forward.T),
+            'sde': lambda rs, x, t: _reverse_coeffs(*forward.sde(x, t), x, t),
+            'discretize': lambda rs, x, t: _reverse_coeffs(*forward.discretize(x, t), x, t),
+        }
+        return type('RSDE', (type(self),), members)()
 
 
 class RVESDE(SDE):
-    """Reflected VE SDE on the unit cube, RD/sde_lib.py:114-161: sigma(t) = sigma_min (sigma_max/sigma_min)^t,
-    zero drift, g(t) = sigma(t) sqrt(2 ln(sigma_max/sigma_min)), uniform prior."""
+    """Variance-exploding SDE reflected on the unit cube (RD/sde_lib.py:114-161):
+    sigma(t) = sigma_min * (sigma_max / sigma_min) ** t, no drift, g(t) = sigma(t) * sqrt(2 ln(sigma_max / sigma_min)),
+    prior U[0,1]^d (log-density 0)."""
 
     def __init__(self, sigma_min=0.01, sigma_max=50, N=1000, T=1):
         super().__init__(N)
-        self.sigma_min = sigma_min
-        self.sigma_max = sigma_max
-        self.discrete_sigmas = torch.exp(torch.linspace(np.log(self.sigma_min), np.log(self.sigma_max), N))
+        self.sigma_min, self.sigma_max, self.T_val = sigma_min, sigma_max, T
         self.N = N
-        self.T_val = T
+        # geometric ladder of the SMLD discretisation
+        self.discrete_sigmas = torch.exp(torch.linspace(math.log(sigma_min), math.log(sigma_max), N))
 
     @property
     def T(self):
@@ -93,12 +92,13 @@ class RVESDE(SDE):
     def _sigma(self, t):
         return self.sigma_min * (self.sigma_max / self.sigma_min) ** t
 
-    def sde(self, x, t):
-        g2 = torch.tensor(2 * (np.log(self.sigma_max) - np.log(self.sigma_min)), device=t.device, dtype=torch.float32)
-        return torch.zeros_like(x), self._sigma(t) * torch.sqrt(g2)
-
     def marginal_prob(self, x, t):
         return x, self._sigma(t)
+
+    def sde(self, x, t):
+        two_log_ratio = torch.tensor(2 * (math.log(self.sigma_max) - math.log(self.sigma_min)), device=t.device,
+                                     dtype=torch.float32)
+        return torch.zeros_like(x), self._sigma(t) * torch.sqrt(two_log_ratio)
 
     def prior_sampling(self, shape):
         return torch.rand(*shape)
@@ -107,9 +107,8 @@ class RVESDE(SDE):
         return torch.zeros_like(z)
 
     def discretize(self, x, t):
-        """SMLD discretisation (RD/sde_lib.py:153-161)."""
-        timestep = (t * (self.N - 1) / self.T).long()
-        sig = self.discrete_sigmas.to(t.device)
-        sigma = sig[timestep]
-        adjacent = torch.where(timestep == 0, torch.zeros_like(t), sig[timestep - 1])
-        return torch.zeros_like(x), torch.sqrt(sigma ** 2 - adjacent ** 2)
+        """SMLD ladder step (RD/sde_lib.py:153-161): G_i = sqrt(sigma_i^2 - sigma_{i-1}^2), sigma_{-1} = 0."""
+        ladder = self.discrete_sigmas.to(t.device)
+        i = (t * (self.N - 1) / self.T).long()
+        below = torch.where(i == 0, torch.zeros_like(t), ladder[i - 1])
+        return torch.zeros_like(x), torch.sqrt(ladder[i] ** 2 - below ** 2)
