@@ -17,28 +17,38 @@
 #include "misc_kernels.h"
 #include "conv_kernel.h"
 
-// G = scale * gY; optional identity-residual accumulation gR += G; one work-item per element.
-__global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_kernel(const float* __restrict__ gY, float* __restrict__ G,
-                                                                  float* __restrict__ gR, float scale, long n) {
-    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const float g = gY[i] * scale;
-    G[i] = g;
-    if (gR) gR[i] += g;
-}
-
-// per-sample column sums of G [NB][HW][C]: gdense[n][off + c] = sum_p G[n][p][c] (optional);
-// bias gradients db[c] (+ db2[c]) += sum_{n,p} G (atomics).  grid = NB, block = 256 (c strided).
-__global__ __launch_bounds__(RDMI_THREADS) void bwd_colsum_kernel(const float* __restrict__ G, float* __restrict__ gdense,
-                                                                   int dense_stride, int dense_off, float* __restrict__ db,
-                                                                   float* __restrict__ db2, int HW, int C) {
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += RDMI_THREADS) {
+// First backward kernel of a conv op, one workgroup per sample: G = scale * gY (the gradient the data- and weight-gradient
+// kernels consume), the identity-residual branch gR += G, and the per-sample column sums of G [HW][C]:
+// gdense[n][off + c] = sum_p G[n][p][c] (Dense_0 path, optional) and the bias gradients db[c] (+ db2[c]) += sum (atomics).
+// 256 work-items = (256 / cw) row lanes x cw columns per pass, partial sums merged in LDS.
+__global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const float* __restrict__ gY, float* __restrict__ G,
+                                                                         float* __restrict__ gR, float scale, float* __restrict__ gdense,
+                                                                         int dense_stride, int dense_off, float* __restrict__ db,
+                                                                         float* __restrict__ db2, int HW, int C) {
+    __shared__ float red[RDMI_THREADS];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c0 = 0; c0 < C; c0 += RDMI_THREADS) {
+        const int cw = min(RDMI_THREADS, C - c0), R = RDMI_THREADS / cw;
+        const int r = tid / cw, c = c0 + tid - r * cw;
         float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += G[((size_t)n * HW + p) * C + c];
-        if (gdense) gdense[(size_t)n * dense_stride + dense_off + c] = s;
-        if (db) atomicAdd(db + c, s);
-        if (db2) atomicAdd(db2 + c, s);
+        if (r < R)
+            for (int p = r; p < HW; p += R) {
+                const size_t i = ((size_t)n * HW + p) * C + c;
+                const float g = gY[i] * scale;
+                G[i] = g;
+                if (gR) gR[i] += g;
+                s += g;
+            }
+        red[tid] = r < R ? s : 0.f;
+        __syncthreads();
+        if (tid < cw) {
+            float tot = 0.f;
+            for (int j = 0; j < R; ++j) tot += red[tid + j * cw];
+            if (gdense) gdense[(size_t)n * dense_stride + dense_off + c] = tot;
+            if (db) atomicAdd(db + c, tot);
+            if (db2) atomicAdd(db2 + c, tot);
+        }
+        __syncthreads();
     }
 }
 

@@ -332,13 +332,9 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         const ConvArgs& fa = op.conv;
         const int Cin = sp.CA + sp.CB;
         const float* gY = op.out_is_output ? grad_out : gptr(op.out_tensor);
-        const long nG = (long)NB * fa.HWo * sp.Cout;
-        // G = scale * gY (+ identity residual)
-        hipLaunchKernelGGL(bwd_scale_kernel, dim3((unsigned)ceil_div((int)nG, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, gY, T.G, gptr(op.tRes),
-                           fa.out_scale, nG);
-        // bias / NIN-bias / Dense_0 gradients
-        hipLaunchKernelGGL(bwd_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, (const float*)T.G, op.use_dense ? T.gdense : (float*)nullptr,
-                           c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout);
+        // G = scale * gY (+ identity residual) and the bias / NIN-bias / Dense_0 gradients (column sums of G)
+        hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, gY, T.G, gptr(op.tRes), fa.out_scale,
+                           op.use_dense ? T.gdense : (float*)nullptr, c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout);
         // data gradient w.r.t. the activated input
         if (b.has_dgrad) {
             ConvArgs d = b.dgrad; d.NB = NB;
