@@ -31,7 +31,7 @@ import weights as W                              # noqa: E402  (oracle/weights.p
 torch.set_num_threads(8)
 
 
-def make_cfg(image_size=9, image_width=9, dropout=0.2, cond_drop_prob=0.5, corrector='none', num_scales=1000):
+def make_cfg(image_size=9, image_width=9, dropout=0.2, cond_drop_prob=0.5, corrector='none', num_scales=1000, warmup=10000):
     return NS(
         model=NS(name='ncsnpp', channels=1, image_size=image_size, image_width=image_width, num_classes=1,
                  cond_drop_prob=cond_drop_prob, conditional=True, init_scale=0., ema_rate=0.999, nf=64,
@@ -41,7 +41,7 @@ def make_cfg(image_size=9, image_width=9, dropout=0.2, cond_drop_prob=0.5, corre
         sampling=NS(method='pc', n_steps_each=1, noise_removal=True, probability_flow=False, snr=0.01,
                     predictor='euler_maruyama', corrector=corrector, denoiser='none'),
         sde=NS(sigma_min=0.01, sigma_max=5, num_scales=num_scales),
-        optim=NS(weight_decay=0, optimizer='Adam', lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, warmup=10000,
+        optim=NS(weight_decay=0, optimizer='Adam', lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, warmup=warmup,
                  grad_clip=0.5),
         training=NS(reduce_mean=False, likelihood_weighting=False))
 
@@ -238,6 +238,51 @@ def gen_train():
     save('train_step.npz', **out)
 
 
+def gen_train_w0():
+    """Optimizer / EMA fixture.  train_step.npz runs the shipped warmup=10000, whose learning rate is 0 at step 0 and 5e-8 at
+    step 1 (RD/losses.py:36-38): the parameter update is below any useful tolerance, so a no-op optimize_fn would pass.
+    Here warmup=0 (the ramp is skipped, lr = 5e-4 from the first step) and three steps are taken, so Adam's moments, the
+    bias correction, clip_grad_norm_(0.5) and the EMA decay schedule min(0.999, (1+n)/(10+n)) all act at full size.
+    Recorded: losses, and for a few parameters the value before, after each step, and the EMA shadow after each step."""
+    cfg = make_cfg(dropout=0.0, cond_drop_prob=0.0, warmup=0)
+    model, _ = ref_model(cfg)
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    B = 8
+    g = torch.Generator().manual_seed(43)
+    batch = torch.rand(B, 1, 9, 9, generator=g)
+    labels = torch.rand(B, 1, generator=g)
+    optimizer = losses.get_optimizer(cfg, model.parameters())
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=optimizer, model=model, ema=ema, step=0, scaler=None)
+    train_step = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=False,
+                                    likelihood_weighting=False)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    watch = ['out_conv.bias', 'out_conv.weight', 'time_mlp.0.bias', 'label_emb.weight', 'down_blocks.0.Conv_0.weight',
+             'mid_block1.Dense_0.weight', 'up_attn.8.NIN_3.W', 'up_blocks.4.GroupNorm_0.weight', 'downsample.1.Conv_0.bias']
+    idx = {n: i for i, (n, _) in enumerate(named)}
+    out = dict(batch=batch.numpy(), labels=labels.numpy(), watch=np.array(watch))
+    for n in watch:
+        out['p0.' + n] = dict(named)[n].detach().numpy().reshape(-1)[:256].copy()      # first 256 values of each watched tensor
+    tvals = torch.tensor([0.05, 0.15, 0.3, 0.45, 0.55, 0.7, 0.85, 0.97], dtype=torch.float32)
+    _rand = torch.rand
+    torch.rand = lambda *a, **k: ((tvals - 1e-5) / (1 - 1e-5)).clone() if a and a[0] == B else _rand(*a, **k)
+    try:
+        for step in range(3):
+            torch.manual_seed(177 + step)
+            with Recorder() as rec:
+                loss = train_step(state, batch, class_labels=labels)
+            out[f'step{step}.t'] = (rec.rand[0] * (1 - 1e-5) + 1e-5).astype(np.float32)
+            out[f'step{step}.z'] = rec.randn[0]
+            out[f'step{step}.loss'] = loss.detach().numpy()
+            for n in watch:
+                out[f'p{step + 1}.' + n] = dict(named)[n].detach().numpy().reshape(-1)[:256].copy()
+                out[f'ema{step + 1}.' + n] = ema.shadow_params[idx[n]].numpy().reshape(-1)[:256].copy()
+    finally:
+        torch.rand = _rand
+    out['num_updates'] = np.int64(ema.num_updates)
+    save('train_step_w0.npz', **out)
+
+
 def gen_init():
     """Reference init under torch.manual_seed(0): lets the build's parameter shell prove it consumes the torch RNG
     identically (same construction order)."""
@@ -296,6 +341,9 @@ def gen_gto_dataset():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['train_w0']:
+        gen_train_w0()
+        sys.exit(0)
     if sys.argv[1:] == ['gto']:
         gen_gto()
         gen_gto_dataset()
@@ -306,4 +354,5 @@ if __name__ == '__main__':
     gen_forward()
     gen_sampler()
     gen_train()
+    gen_train_w0()
     gen_init()

@@ -279,3 +279,64 @@ def test_training_steps_match_reference(env, golden):
     g = golden('train_step.npz')
     out = _train_two_steps(env['ge'], 'cpu', g)
     check_train_against_reference(out, g, rtol_norm=2e-4)
+
+
+def _train_steps_w0(ge, dev, g, nsteps):
+    """Reference-shaped training steps with warmup=0 (full learning rate from step 0) and the recorded (t, z)."""
+    from rdmi import losses, sde_lib
+    from rdmi.models.ema import ExponentialMovingAverage
+    model, cfg, _ = ge.make_model(dev)
+    model.dropout, model.cond_drop_prob = 0.0, 0.0
+    cfg.optim.warmup = 0
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    optimizer = losses.get_optimizer(cfg, model.parameters())
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=optimizer, model=model, ema=ema, step=0, scaler=None)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=False,
+                                 likelihood_weighting=False)
+    batch, labels = torch.from_numpy(g['batch']).to(dev), torch.from_numpy(g['labels']).to(dev)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    idx = {n: i for i, (n, _) in enumerate(named)}
+    watch = [str(n) for n in g['watch']]
+    out = {'p0': {n: dict(named)[n].detach().cpu().numpy().reshape(-1)[:256].copy() for n in watch}}
+    _r, _n = torch.rand, torch.randn_like
+    try:
+        for k in range(nsteps):
+            tv, zv = torch.from_numpy(g[f'step{k}.t']).to(dev), torch.from_numpy(g[f'step{k}.z']).to(dev)
+            torch.rand = lambda *a, tv=tv, **kw: ((tv - 1e-5) / (1 - 1e-5)).clone()
+            torch.randn_like = lambda x, zv=zv, **kw: zv.clone()
+            out[f'loss{k}'] = float(step_fn(state, batch, class_labels=labels).detach())
+            out[f'p{k + 1}'] = {n: dict(named)[n].detach().cpu().numpy().reshape(-1)[:256].copy() for n in watch}
+            out[f'ema{k + 1}'] = {n: ema.shadow_params[idx[n]].cpu().numpy().reshape(-1)[:256].copy() for n in watch}
+    finally:
+        torch.rand, torch.randn_like = _r, _n
+    out['state'], out['ema'] = state, ema
+    return out
+
+
+def check_train_w0_against_reference(out, g, nsteps, rtol_loss=2e-3):
+    """Adam (bias-corrected moments, eps), clip_grad_norm_(0.5) and the EMA schedule against the reference's recorded run,
+    compared as UPDATES (p_k - p_0): a no-op optimizer or EMA fails by 100 %.  Tolerance: step 1 moves every weight by
+    lr * g/(|g| + 1e-8) = +-5e-4 exactly unless |g| ~ 1e-8; later steps divide by sqrt(v) of fp32 gradients that agree to
+    ~1e-4 relative, so 1 % of the largest update per tensor (elements whose gradient changes sign move by < that)."""
+    for k in range(nsteps):
+        np.testing.assert_allclose(out[f'loss{k}'], float(g[f'step{k}.loss']), rtol=2e-5 if k == 0 else rtol_loss)
+    for n in [str(x) for x in g['watch']]:
+        p0 = g['p0.' + n]
+        np.testing.assert_array_equal(out['p0'][n], p0)
+        for k in range(1, nsteps + 1):
+            du, dr = out[f'p{k}'][n] - p0, g[f'p{k}.' + n] - p0
+            assert np.abs(dr).max() > 1e-5, n                       # the reference really moved
+            np.testing.assert_allclose(du, dr, rtol=0, atol=0.01 * np.abs(dr).max(), err_msg=f'{n} after step {k}')
+            eu, er = out[f'ema{k}'][n] - p0, g[f'ema{k}.' + n] - p0
+            assert np.abs(er).max() > 1e-6, n
+            np.testing.assert_allclose(eu, er, rtol=0, atol=0.01 * np.abs(er).max(), err_msg=f'EMA {n} after step {k}')
+    assert out['state']['step'] == nsteps and out['ema'].num_updates == nsteps
+
+
+def test_optimizer_and_ema_updates_match_reference(env, golden):
+    """The optimizer / EMA half of losses.get_step_fn at full learning rate (fixture train_step_w0.npz, warmup=0): two
+    steps on the emulator (the GPU test runs all three recorded steps)."""
+    g = golden('train_step_w0.npz')
+    out = _train_steps_w0(env['ge'], 'cpu', g, 2)
+    check_train_w0_against_reference(out, g, 2)
