@@ -64,6 +64,9 @@ struct LinArgs {
     int use_scalar; float t_scalar;                 // X == null: every row uses this one time (the PC loop, RD/sampling.py:329)
     // optional label embedding added in the epilogue: labels [label_rows][ncls] (rows beyond are zero labels)
     const float* labels; const float* Wl; const float* bl; int ncls; int label_rows;
+    // pre == 3 with row_div > 0: row r is (update r / row_div, sample r % row_div): X row = r / row_div, labels of sample r % row_div
+    // (the sampler's Dense_0 outputs for a whole chunk of updates in one launch, see rdmi_pc_sample)
+    int row_div;
 };
 
 __device__ __forceinline__ float sigma_of(float v, int t_is_time, float smin, float ratio) {
@@ -106,10 +109,11 @@ __global__ __launch_bounds__(RDMI_THREADS) void linear_mfma_kernel(LinArgs a) {
                     af[j] = k < a.nfour ? sinf(arg) : cosf(arg);
                 }
             } else {
-                af = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + k0);
-                if (a.pre == 3 && a.labels && row < a.label_rows)      // same order of additions as the time_mlp.2 epilogue below
+                const int xrow = a.row_div > 0 ? row / a.row_div : row, srow = a.row_div > 0 ? row - xrow * a.row_div : row;
+                af = *reinterpret_cast<const f32x4*>(a.X + (size_t)xrow * a.ldx + k0);
+                if (a.pre == 3 && a.labels && srow < a.label_rows)     // same order of additions as the time_mlp.2 epilogue below
                     for (int j = 0; j < 4; ++j)
-                        for (int c = 0; c < a.ncls; ++c) af[j] += a.labels[(size_t)row * a.ncls + c] * a.Wl[(size_t)(k0 + j) * a.ncls + c];
+                        for (int c = 0; c < a.ncls; ++c) af[j] += a.labels[(size_t)srow * a.ncls + c] * a.Wl[(size_t)(k0 + j) * a.ncls + c];
                 if (a.pre == 1 || a.pre == 3)
                     for (int j = 0; j < 4; ++j) af[j] = silu_f(af[j]);
             }
@@ -324,6 +328,20 @@ __global__ __launch_bounds__(RDMI_THREADS) void teacher_copy_kernel(float* __res
 // advance the device-resident loop state (single work-item; stream order makes it race-free)
 __global__ void step_advance_kernel(StepState* st, int dstep, int ddraw) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->step += dstep; st->draw += ddraw; }
+}
+
+// timesteps = torch.linspace(start, end, N)[0:n] on the device: fp32 step, value i = start + step*i in the first half and
+// end - step*(N-1-i) in the second (ATen's linspace kernel), evaluated in double WITHOUT contraction into an fma so that it
+// reproduces the host-side copy of the same expression bit for bit (rdmi_pc_sample passes that copy to the update kernels).
+__global__ __launch_bounds__(RDMI_THREADS) void linspace_kernel(float* __restrict__ ts, int n, int N, float start, float end) {
+    const int i = blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const double step = (double)(float)((end - start) / (float)(N - 1));
+#if defined(__HIP_DEVICE_COMPILE__)
+    ts[i] = (float)(i < N / 2 ? __dadd_rn((double)start, __dmul_rn(step, (double)i)) : __dsub_rn((double)end, __dmul_rn(step, (double)(N - 1 - i))));
+#else
+    ts[i] = (float)(i < N / 2 ? (double)start + step * i : (double)end - step * (N - 1 - i));
+#endif
 }
 
 // fill a [M] vector with ts[step] (all samples share one time per update, RD/sampling.py:329)

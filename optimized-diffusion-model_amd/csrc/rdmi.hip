@@ -133,6 +133,7 @@ struct rdmi_ctx {
     // sampler scratch
     float *d_s2 = nullptr, *d_score = nullptr, *d_z = nullptr, *d_norms = nullptr, *d_ts = nullptr, *d_tvec = nullptr;
     float *d_tt = nullptr, *d_th1 = nullptr; int tt_cap = 0;   // sampler: time-path rows of all updates (rdmi_pc_sample)
+    float* d_dense_all = nullptr; size_t dense_all_cap = 0;    // sampler: Dense_0 outputs of a chunk of updates [U][NBm][dense_total]
     int ts_cap = 0;
     StepState* d_state = nullptr;
     // fused (workgroup-resident) path
@@ -656,6 +657,9 @@ struct FusedBuilder {
     size_t spill_floats = 0;
     bool failed = false;
     std::string why;
+    int gn_slot_off = 0;            // LDS byte offset of the fused-GroupNorm partial-sum slots (2 KiB)
+    bool gn_fuse = true;            // RDMI_NO_GNFUSE=1 keeps every GroupNorm its own op (A/B and debugging)
+    int n_gn_fused = 0, n_gn_ops = 0;
 
     void fail_(const std::string& m) { if (!failed) { failed = true; why = m; } }
 
@@ -754,7 +758,7 @@ struct FusedBuilder {
     FOp blank(int kind) {
         FOp o;
         std::memset(&o, 0, sizeof o);
-        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1;
+        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1; o.gn_off = -1;
         return o;
     }
     int emit(const FOp& o) { c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
@@ -795,7 +799,34 @@ struct FusedBuilder {
         spill_fix.push_back({idx, off, false});
         return off;
     }
+    // GroupNorm (+SiLU) of tensor t (in place), or of `src` into t (copy form).  When the tensor being normalised is the
+    // output of the CONV op emitted just before (only STOREs in between), has 4-channel groups and the conv's tiling gives
+    // every wave a single pass, the GroupNorm is folded into that conv's epilogue (FOp::gn_*) and no op is emitted.
+    bool try_fuse_gn(const LT& t, const std::string& pre, bool act, const LT* src) {
+        if (!gn_fuse) return false;
+        const LT& in = src ? *src : t;
+        int j = (int)c->fprog.size() - 1;
+        while (j >= 0 && c->fprog[(size_t)j].kind == FOP_STORE) --j;
+        if (j < 0) return false;
+        FOp& p = c->fprog[(size_t)j];
+        if (p.kind != FOP_CONV || p.dst_kind != 0 || p.gn_off >= 0 || p.dst_off != in.off || p.dst_rs != in.rs) return false;
+        if (p.Cout != t.C || p.rows != t.rows() || t.C % 4 != 0 || std::min(t.C / 4, 32) * 4 != t.C) return false;      // Cg == 4 only
+        const int ntiles = p.Cout_pad >> 4;
+        const int lWN = (ntiles >= 8 && (ntiles & 7) == 0) ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // as fop_conv
+        const int WN = 1 << lWN, WM = UW_WAVES >> lWN;
+        if (ntiles > WN || p.mtiles > 4 * WM) return false;                    // a wave would make several passes
+        const int nslots = WM * 4;
+        if ((t.C / 4) * nslots * 8 > 1024) return false;
+        p.gn_off = t.off; p.gn_rs = t.rs; p.gn_act = act ? 1 : 0; p.gn_raw = src ? 1 : 0;
+        p.gn_slot_off = gn_slot_off; p.gn_nslots = nslots;
+        p.eps = 1e-6f; p.inv_cnt = 1.0f / (float)(4 * t.rows());
+        patch_param(j, F_GAMMA, pre + ".weight"); patch_param(j, F_BETA, pre + ".bias");
+        ++n_gn_fused;
+        return true;
+    }
     void gn(const LT& t, const std::string& pre, bool act, const LT* src = nullptr) {
+        if (try_fuse_gn(t, pre, act, src)) return;
+        ++n_gn_ops;
         FOp o = blank(FOP_GN);
         if (src) { o.src_off = src->off; o.src_rs = src->rs; }
         o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
@@ -942,8 +973,10 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     }
     // LDS: [row tables] [zero row] [GN stats] [tensor arena]
     const int zero_bytes = 1280;                     // >= (Cmax/16)*64 + 64 for Cmax = 256... host-checked below
-    const int stat_bytes = 256 + 2 * (int)sizeof(FOp) + 64;   // GN scratch + two staged op descriptors
+    const int stat_bytes = 1024 + 64;                         // GN op scratch [2 x 32] overlaid with the fused-GroupNorm partial-sum slots (never live together)
     b.arena_init(TAB_RESERVE + zero_bytes + stat_bytes);
+    b.gn_slot_off = TAB_RESERVE + zero_bytes;
+    b.gn_fuse = std::getenv("RDMI_NO_GNFUSE") == nullptr;
     int H = c->H, W = c->W;
     if (H * W > 96) { c->fused_why = "more than 96 pixels per sample"; return 0; }
 
@@ -1043,7 +1076,7 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     for (auto& o : c->fprog) {
         char buf[160];
         const char* kn[] = {"GATHER", "STORE", "GN", "CONV", "ATTN"};
-        if (o.kind == FOP_CONV) snprintf(buf, sizeof buf, "CONV rows=%d mtiles=%d K=%dx%d(+%d) Cout=%d dst=%d", o.rows, o.mtiles, o.ntap, o.main_ph.nch * 16, o.nsc ? o.sc[0].nch * 16 : 0, o.Cout, o.dst_kind);
+        if (o.kind == FOP_CONV) snprintf(buf, sizeof buf, "CONV rows=%d mtiles=%d K=%dx%d(+%d) Cout=%d dst=%d%s", o.rows, o.mtiles, o.ntap, o.main_ph.nch * 16, o.nsc ? o.sc[0].nch * 16 : 0, o.Cout, o.dst_kind, o.gn_off >= 0 ? (o.gn_raw ? " +GN(copy)" : " +GN") : "");
         else snprintf(buf, sizeof buf, "%s rows=%d C=%d", kn[o.kind], o.rows, o.C);
         c->fdesc.push_back(buf);
     }
@@ -1177,6 +1210,7 @@ struct FwdIn {
     const float* labels; int label_rows;
     float* out; int NB;
     const float* tt_row = nullptr;        // sampler: precomputed time_mlp.2 output row (+ both biases) of this evaluation's t
+    const float* dense_rows = nullptr;    // sampler: precomputed Dense_0 outputs [NB][dense_total] of this evaluation (skips the whole embedding)
 };
 
 int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
@@ -1186,7 +1220,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     if (a.conditional && !f.labels) return fail("class_labels is required: the model is conditional (label_emb) -- reference raises here too (RD/models/ncsnpp.py:262)");
     const int T = c->temb, Np_t = (T + 63) & ~63, Np_d = (c->dense_total + 63) & ~63;
     // ---- embedding: Fourier -> Linear -> SiLU -> Linear (+label_emb) -> [SiLU -> all Dense_0]
-    if (!f.tt_row) {
+    if (!f.tt_row && !f.dense_rows) {
     LinArgs l{};
     l.M = f.NB; l.fourW = P(c, "time_embed.W"); l.nfour = a.nf;
     l.X = f.sig; l.x_mod = f.sig_mod > 0 ? f.sig_mod : f.NB; l.t_is_time = f.t_is_time; l.smin = f.smin; l.ratio = f.ratio;
@@ -1206,6 +1240,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
         hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l2);
     }
     }
+    if (!f.dense_rows) {
     LinArgs l3{};
     l3.M = f.NB; l3.X = c->d_temb; l3.ldx = T; l3.pre = 1; l3.K = T;
     if (f.tt_row) {     // every sample shares the time row; the label embedding is added in the prologue (same sums as time_mlp.2's epilogue)
@@ -1216,6 +1251,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     {
         ProfScope ps(c, s, "linear_mfma(Dense_0 x all)", 2.0 * f.NB * T * c->dense_total);
         hipLaunchKernelGGL((linear_mfma_kernel<1, 16>), dim3((unsigned)ceil_div(f.NB, 16), (unsigned)(Np_d / 64)), dim3(RDMI_THREADS), 0, s, l3);
+    }
     }
     HIP_OK(hipGetLastError());
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
@@ -1228,6 +1264,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
         }
         UnetArgs ua = c->fargs;
         ua.x_in = f.x; ua.x_mod = f.x_mod; ua.out = f.out; ua.NB = f.NB;
+        if (f.dense_rows) ua.dense = f.dense_rows;
         double fl = 0;
         for (auto& op : c->ops) fl += op.flops_per_sample;
         ProfScope ps(c, s, "unet_wg_kernel", fl * f.NB);
@@ -1243,6 +1280,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
             ca.NB = f.NB;
             if (op.a_is_input) { ca.srcA = f.x; ca.srcA_mod = f.x_mod; }
             if (op.out_is_output) ca.out = f.out;
+            if (op.use_dense && f.dense_rows) ca.dense = f.dense_rows;
             ProfScope ps(c, s, cfg_name(op.cfg), op.flops_per_sample * f.NB);
             if (int e = launch_conv(op.cfg, ca, s)) return e;
         } else {
@@ -1325,7 +1363,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         train_registry().erase(c);
         delete T;
     }
-    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1};
+    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete c;
@@ -1524,7 +1562,7 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
     // update's t, which is known up front: evaluate it for ALL updates in two launches (one row per update) instead of two
     // launches per score evaluation; per evaluation only the batched Dense_0 GEMM remains, which adds the label embedding
     // to the shared row in its prologue.
-    const int nupd = o->N - 1, T = c->temb, Np_t = (T + 63) & ~63;
+    const int nupd = o->N - 1, T = c->temb, Np_t = (T + 63) & ~63, Np_d = (c->dense_total + 63) & ~63;
     if (c->tt_cap < nupd) {
         if (c->d_tt) { HIP_OK(hipFree(c->d_tt)); HIP_OK(hipFree(c->d_th1)); HIP_OK(hipFree(c->d_ts)); c->d_tt = c->d_th1 = c->d_ts = nullptr; c->tt_cap = 0; }
         HIP_OK(hipMalloc((void**)&c->d_tt, (size_t)pad16(nupd) * T * sizeof(float)));
@@ -1532,9 +1570,11 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
         HIP_OK(hipMalloc((void**)&c->d_ts, (size_t)pad16(nupd) * sizeof(float)));
         c->tt_cap = nupd;
     }
+    const rdmi_arch& a = c->arch;
     {
-        HIP_OK(hipMemcpyAsync(c->d_ts, ts.data(), (size_t)nupd * sizeof(float), hipMemcpyHostToDevice, s));
-        const rdmi_arch& a = c->arch;
+        // the time grid is formed on the device by the same double-precision expression as the host copy above (no host
+        // buffer has to outlive this call: every rdmi entry point is asynchronous on `stream`)
+        hipLaunchKernelGGL(linspace_kernel, dim3((unsigned)ceil_div(nupd, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, c->d_ts, nupd, o->N, 1.0f, o->eps);
         LinArgs l{};
         l.M = nupd; l.fourW = P(c, "time_embed.W"); l.nfour = a.nf; l.X = c->d_ts; l.x_mod = nupd; l.t_is_time = 1; l.smin = smin; l.ratio = ratio;
         l.pre = 2; l.K = pad16(2 * a.nf); l.W = c->d_w + c->w_t0; l.Npad = Np_t; l.N = T; l.bias = P(c, "time_mlp.0.bias"); l.Y = c->d_th1; l.ldy = T;
@@ -1546,17 +1586,41 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
         hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(nupd, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l);
         hipLaunchKernelGGL(linear_mfma_kernel<1>, dim3((unsigned)ceil_div(nupd, 16), (unsigned)(Np_t / 64)), dim3(RDMI_THREADS), 0, s, l2);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(s));      // ts (host vector) must outlive the copy; once per sampling call
     }
+    // Dense_0 (the 17 per-block projections of SiLU(temb), RD/models/layerspp.py:202) depends on (update, sample) only through
+    // the update's time row and the sample's label: it is evaluated for a whole CHUNK of updates in one GEMM launch
+    // ([U * NBm] rows: a real dense contraction instead of 999 launches of 256 rows) into a buffer of at most ~256 MB;
+    // row (u, n) = Dense_0(SiLU(tt[u] + label_emb(labels[n]))): the same sums in the same order as the stand-alone path.
+    const size_t dense_row_floats = (size_t)NBm * c->dense_total;
+    const int U = (int)std::max<size_t>(1, std::min<size_t>((size_t)nupd, ((size_t)256 << 20) / (dense_row_floats * sizeof(float))));
+    if (c->dense_all_cap < (size_t)U * dense_row_floats) {
+        if (c->d_dense_all) { HIP_OK(hipFree(c->d_dense_all)); c->d_dense_all = nullptr; c->dense_all_cap = 0; }
+        HIP_OK(hipMalloc((void**)&c->d_dense_all, (size_t)U * dense_row_floats * sizeof(float)));
+        c->dense_all_cap = (size_t)U * dense_row_floats;
+    }
+    auto dense_chunk = [&](int i0) -> int {
+        const int u = std::min(U, nupd - i0);
+        LinArgs l3{};
+        l3.M = u * NBm; l3.X = c->d_tt + (size_t)i0 * T; l3.ldx = T; l3.pre = 3; l3.K = T; l3.row_div = NBm;
+        if (a.conditional && labels) { l3.labels = labels; l3.Wl = P(c, "label_emb.weight"); l3.ncls = a.num_classes; l3.label_rows = B; }
+        l3.W = c->d_w + c->w_dense; l3.Npad = Np_d; l3.N = c->dense_total;
+        l3.bias = c->d_w + c->b_dense; l3.Y = c->d_dense_all; l3.ldy = c->dense_total;
+        ProfScope ps(c, s, "linear_mfma(Dense_0 x all, chunk of updates)", 2.0 * l3.M * T * c->dense_total);
+        hipLaunchKernelGGL((linear_mfma_kernel<1, 16>), dim3((unsigned)ceil_div(l3.M, 16), (unsigned)(Np_d / 64)), dim3(RDMI_THREADS), 0, s, l3);
+        HIP_OK(hipGetLastError());
+        return 0;
+    };
     // one score evaluation at update i's shared time: the raw network output lands in d_s2 ([2B] with CFG, [B] without)
     auto net_eval = [&](int i, float t) -> int {
         FwdIn f{x, o->use_cfg ? B : 0, nullptr, 0, t, 1, smin, ratio, labels, B, c->d_s2, NBm};
         f.tt_row = c->d_tt + (size_t)i * T;
+        f.dense_rows = c->d_dense_all + (size_t)(i % U) * dense_row_floats;
         return run_forward(c, f, s);
     };
     uint32_t draw = 0;
     for (int i = 0; i < o->N - 1; ++i) {
         const float t = ts[(size_t)i];
+        if (i % U == 0) { if (int e = dense_chunk(i)) return e; }
         if (o->corrector == 1) {
             for (int k = 0; k < o->n_steps_each; ++k, ++draw) {
                 if (int e = net_eval(i, t)) return e;

@@ -131,6 +131,7 @@ class Context:
         self.device = torch.device(device)
         self.max_batch, self.H, self.W = max_batch, H, W
         self._h = C.c_void_p()
+        self._owner = lib()              # the library that creates the context is the one that destroys it
         with self._guard():
             check(lib().rdmi_create(C.byref(arch), max_batch, H, W, C.byref(self._h)))
         self._bound = {}
@@ -155,7 +156,7 @@ class Context:
 
     def close(self):
         if self._h:
-            lib().rdmi_destroy(self._h)
+            self._owner.rdmi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

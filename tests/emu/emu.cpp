@@ -131,6 +131,11 @@ static void run_block(void (*tramp)(void*), void* args, dim3 bid, dim3 grid, dim
         if (!progress) {
             std::fprintf(stderr, "emu: deadlock in block (%u,%u): %d/%d done, block barrier %d/%d\n", bid.x, bid.y,
                          done, nt, b.arrived, b.live);
+            for (size_t wv = 0; wv < b.waves.size(); ++wv) {
+                int nw = 0, nb = 0;
+                for (int i = (int)wv * 64; i < std::min<int>((int)wv * 64 + 64, nt); ++i) { nw += b.lanes[i].state == WAIT_WAVE; nb += b.lanes[i].state == WAIT_BLOCK; }
+                std::fprintf(stderr, "emu:   wave %zu: %d lanes in a wave collective, %d at the block barrier\n", wv, nw, nb);
+            }
             std::abort();
         }
     }
