@@ -33,7 +33,36 @@ PEAK_HBM_GBPS = 8000.0
 GFLOP_PER_FORWARD = 0.220438528        # 110 219 264 MAC per sample-forward at 9x9
 ACT_BYTES_PER_FORWARD = 4440464        # layer-granular activation bytes per sample-forward
 WEIGHT_BYTES = 25019652
-PMC_TRAFFIC_BYTES_UNET_B128 = (2 * 98287 + 15576) * 1024   # profiles/r01_pmc_hbm_traffic_unet_wg_kernel.md
+GFLOP_PER_FORWARD_8X9 = 0.207374848    # 103 687 424 MAC at 8x9
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'unet_traffic.json')   # written by scripts/pmc_traffic_to_json.py from rocprofv3 --pmc passes
+
+
+def csrc_sha16():
+    """Hash of the kernel sources: a PMC traffic figure is only quoted for the binary it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'optimized-diffusion-model_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), 'rb') as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel, B, hw):
+    """(bytes per launch | None, note): the HBM-side bytes of the dominant kernel come from separate rocprofv3 --pmc passes
+    (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE; they cannot be collected inside this
+    process).  The figure is emitted only when it was measured on these kernel sources at this shape."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+    except Exception as e:                                       # noqa: BLE001
+        return None, f'no {os.path.relpath(TRAFFIC_JSON, ROOT)} ({e.__class__.__name__})'
+    if t.get('kernel') != kernel or t.get('batch') != B or t.get('pixels') != hw:
+        return None, f"{os.path.relpath(TRAFFIC_JSON, ROOT)} holds {t.get('kernel')} at B={t.get('batch')}, {t.get('pixels')} px: not this run's shape"
+    if t.get('csrc_sha16') != csrc_sha16():
+        return None, f"stale: measured on csrc {t.get('csrc_sha16')} (commit {t.get('commit')}), this run is csrc {csrc_sha16()}"
+    return t['bytes_per_launch'], (f"rocprofv3 --pmc passes on commit {t.get('commit')}: FETCH_SIZE {t.get('fetch_size_kb_mean')} KB x2 "
+                                   f"(gfx950 correction) + WRITE_SIZE {t.get('write_size_kb_mean')} KB per launch; {t.get('source')}")
 
 
 def main():
@@ -48,6 +77,7 @@ def main():
     ap.add_argument('--width', type=int, default=9)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-variants', action='store_true', help='skip the Langevin / [1,8,9] / training-step variant measurements')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -128,6 +158,8 @@ def main():
     }
     if rank == 0 and not args.no_roofline:
         out['roofline'] = roofline(ge, model, cfg, sde, shape, labels, dev, args, value / world, fwd_per_traj)
+    if rank == 0 and world == 1 and not args.no_variants and not args.no_roofline:
+        out['variants'] = variants(ge, dev, args, labels)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, B)
     if rank == 0:
@@ -137,13 +169,13 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, fwd_per_traj):
-    """Instrumented pass: HIP events around every launch (csrc ProfScope), 60 updates of the same batch."""
+def profile_pass(model, cfg, shape, labels, dev, corrector):
+    """Instrumented pass: HIP events around every launch on the launch stream (csrc ProfScope), 60 updates of the batch."""
     from rdmi import sampling, sde_lib
     N = 61
     sde2 = sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=N)
     fn = sampling.get_pc_sampler(sde2, shape, sampling.get_predictor('euler_maruyama'),
-                                 sampling.get_corrector(args.corrector), sampling.get_denoiser('none'), cfg.sampling.snr,
+                                 sampling.get_corrector(corrector), sampling.get_denoiser('none'), cfg.sampling.snr,
                                  cfg.sampling.n_steps_each, 1e-5, dev, seed=7)
     fn(model, weight=0.0, class_labels=labels)                 # warm
     ctx = model._ctx[(str(dev), shape[2], shape[3])]
@@ -152,7 +184,11 @@ def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, 
     torch.cuda.synchronize()
     prof = ctx.get_profile()
     ctx.set_profiling(False)
-    plan = ctx.path_info()
+    return prof, ctx.path_info()
+
+
+def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, fwd_per_traj):
+    prof, plan = profile_pass(model, cfg, shape, labels, dev, args.corrector)
     total_ms = sum(p['ms'] for p in prof)
     dom = max(prof, key=lambda p: p['ms'])
     achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
@@ -160,46 +196,113 @@ def roofline(ge, model, cfg, sde, shape, labels, dev, args, traj_per_s_per_gpu, 
                              'share': p['ms'] / total_ms, 'tflops': (p['flops'] / (p['ms'] * 1e-3) / 1e12) if p['flops'] else None}
                for p in sorted(prof, key=lambda p: -p['ms'])}
     hbm_bytes_per_traj = fwd_per_traj * ACT_BYTES_PER_FORWARD + (fwd_per_traj / 2) * WEIGHT_BYTES / shape[0]
-    # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
-    # they cannot be collected from inside this process): profiles/r01_pmc_hbm_traffic_unet_wg_kernel.md, B=128 shape only.
-    traffic = PMC_TRAFFIC_BYTES_UNET_B128 if (dom['kernel'] == 'unet_wg_kernel' and shape[0] == 128 and shape[2] * shape[3] == 81) else None
+    traffic, note = measured_traffic(dom['kernel'], shape[0], shape[2] * shape[3])
     return {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-            'traffic_note': 'bytes/launch from rocprofv3 PMC passes of this command, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; see profiles/',
+            'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_note': note,
             'avg_launch_us': 1e3 * dom['ms'] / max(dom['launches'], 1), 'launches': dom['launches'], 'plan': plan,
             'whole_path_frac_of_fp32_peak': traj_per_s_per_gpu * fwd_per_traj * GFLOP_PER_FORWARD / 1e3 / PEAK_FP32_MFMA_TFLOPS,
             'whole_path_layer_granular_hbm_frac': traj_per_s_per_gpu * hbm_bytes_per_traj / 1e9 / PEAK_HBM_GBPS,
             'kernels': kernels}
 
 
+def variants(ge, dev, args, labels):
+    """The other configurations BASELINE.md 5 asks for, measured in this same run (rank 0, N=1): C2' Langevin corrector,
+    the [1,8,9] shape BASELINE.json names, and C4 the score-matching training step at B=128.  Sampler variants: one warm
+    call at a short schedule, then ONE full 1000-scale call timed device-synchronised; `frac` = the dominant kernel's
+    algorithmic FLOP over its mean HIP-event launch time, as for the headline."""
+    from rdmi import sampling, sde_lib
+    B = args.batch
+    out = {}
+    for name, corr, H, W in (('langevin', 'langevin', 9, 9), ('shape_8x9', 'none', 8, 9)):
+        model, cfg, _ = ge.make_model(dev, corrector=corr, num_scales=args.num_scales, image_size=9, image_width=W)
+        shape = (B, 1, H, W)
+        prof, plan = profile_pass(model, cfg, shape, labels, dev, corr)
+        dom = max(prof, key=lambda p: p['ms'])
+        sde = sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=cfg.sde.num_scales)
+        fn = sampling.get_sampling_fn(cfg, sde, shape, 1e-5, dev)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        x, nfe = fn(model, weight=0.0, class_labels=labels)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
+        gf = GFLOP_PER_FORWARD if H * W == 81 else GFLOP_PER_FORWARD_8X9
+        out[name] = {'value': B / dt, 'unit': 'trajectories/s', 'ms_per_call': 1e3 * dt, 'nfe': nfe,
+                     'kernel': dom['kernel'], 'avg_launch_us': 1e3 * dom['ms'] / max(dom['launches'], 1),
+                     'frac': (dom['flops'] / (dom['ms'] * 1e-3) / 1e12) / PEAK_FP32_MFMA_TFLOPS,
+                     'whole_path_frac_of_fp32_peak': (B / dt) * 2 * (args.num_scales - 1) * (2 if corr == 'langevin' else 1) * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS}
+        del model
+    out['train_b128'] = train_variant(ge, dev, 128)
+    return out
+
+
+def train_variant(ge, dev, B, steps=10):
+    """BASELINE config #4 shape: losses.get_step_fn(train=True) -- HIP forward (dropout 0.2, label drop 0.5) + loss + HIP
+    backward + clip + Adam + EMA -- at batch B.  FLOP = 3 x forward (forward, data gradient, weight gradient)."""
+    from rdmi import losses, sde_lib
+    from rdmi.models.ema import ExponentialMovingAverage
+    model, cfg, _ = ge.make_model(dev)
+    model.train()
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=opt, model=model, ema=ema, step=0, scaler=None)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=False,
+                                 likelihood_weighting=False)
+    g = torch.Generator().manual_seed(5)
+    batch = torch.rand(B, 1, 9, 9, generator=g).to(dev); lab = torch.rand(B, 1, generator=g).to(dev)
+    for _ in range(3):
+        loss = step_fn(state, batch, class_labels=lab)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step_fn(state, batch, class_labels=lab)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(loss.detach()))
+    tf = 3 * GFLOP_PER_FORWARD * B / dt / 1e3
+    return {'ms_per_step': 1e3 * dt, 'samples_per_s': B / dt, 'batch': B, 'dtype': getattr(model, 'train_dtype', 'f32'), 'tflops': tf,
+            'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'loss': float(loss.detach()),
+            'what': 'train-mode forward + score-matching loss + backward + clip_grad_norm_ + Adam + EMA, steps timed back to back'}
+
+
 def cpu_baseline(args, B):
-    """torch-CPU restatement (oracle/rd_oracle_torch.py), all host threads, a bounded sample of the same workload."""
-    import numpy as np
+    """torch-CPU restatement (oracle/rd_oracle_torch.py) on a bounded sample of the same workload.  81-pixel convolutions do
+    not scale to every core of a large host (oneDNN over-threading made 128 threads slower than 8 in round 1), so a short
+    sweep over thread counts is timed and the BEST is reported with its `cores`."""
+    import numpy as np  # noqa: F401
     from oracle import rd_oracle as O
     from oracle import rd_oracle_torch as OT
     from oracle.weights import make_params
     p = {k: torch.from_numpy(v) for k, v in make_params(0).items()}
     g = torch.Generator().manual_seed(1)
-    x = torch.rand(B, 1, args.height, args.width, generator=g)
+    x0 = torch.rand(B, 1, args.height, args.width, generator=g)
     lab = torch.rand(B, 1, generator=g)
     w = torch.zeros(B)
     ts = O.torch_linspace(1, 1e-5, args.num_scales)
     lang = args.corrector == 'langevin'
-    n, t_used = 0, 0.0
-    with torch.no_grad():
-        OT.pc_update(p, x, torch.full((B,), float(ts[0])), lab, w, torch.randn(x.shape, generator=g), args.num_scales)   # warm
-        while t_used < 12.0 and n < 200:
-            t = torch.full((B,), float(ts[min(n * 5, args.num_scales - 2)]))
-            zp = torch.randn(x.shape, generator=g)
-            zc = torch.randn(x.shape, generator=g) if lang else None
-            t0 = time.perf_counter()
-            x = OT.pc_update(p, x, t, lab, w, zp, args.num_scales, z_corr=zc)
-            t_used += time.perf_counter() - t0
-            n += 1
-    per_update = t_used / n
-    return {'value': B / (per_update * (args.num_scales - 1)), 'unit': 'trajectories/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'host_cpus': os.cpu_count(),
-            'sample': f'{n} PC updates of the same B={B} CFG batch ({t_used:.1f} s), scaled to {args.num_scales - 1} updates'}
+    ncpu = os.cpu_count() or 1
+    sweep = sorted({min(n, ncpu) for n in (8, 16, 32, 64, 128)})
+    results = {}
+    best = None
+    for nthr in sweep:
+        torch.set_num_threads(nthr)
+        x = x0.clone()
+        n, t_used = 0, 0.0
+        with torch.no_grad():
+            OT.pc_update(p, x, torch.full((B,), float(ts[0])), lab, w, torch.randn(x.shape, generator=g), args.num_scales)   # warm
+            while t_used < 4.0 and n < 200:
+                t = torch.full((B,), float(ts[min(n * 5, args.num_scales - 2)]))
+                zp = torch.randn(x.shape, generator=g)
+                zc = torch.randn(x.shape, generator=g) if lang else None
+                t0 = time.perf_counter()
+                x = OT.pc_update(p, x, t, lab, w, zp, args.num_scales, z_corr=zc)
+                t_used += time.perf_counter() - t0
+                n += 1
+        v = B / ((t_used / n) * (args.num_scales - 1))
+        results[str(nthr)] = round(v, 4)
+        if best is None or v > best[0]:
+            best = (v, nthr, n, t_used)
+    return {'value': best[0], 'unit': 'trajectories/s', 'cores': best[1], 'kind': 'port', 'host_cpus': ncpu,
+            'threads_sweep': results,
+            'sample': f'{best[2]} PC updates of the same B={B} CFG batch ({best[3]:.1f} s) per thread count, scaled to '
+                      f'{args.num_scales - 1} updates; best of the sweep'}
 
 
 if __name__ == '__main__':

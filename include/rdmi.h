@@ -165,6 +165,31 @@ int rdmi_pc_sample(rdmi_ctx* ctx, float* x, const float* labels, const float* we
                    float* trace, const float* teacher, int B, const rdmi_pc_opts* opts, unsigned flags,
                    void* stream);
 
+/* ---- multi-tensor optimizer step -------------------------------------------------------------
+ * Replaces, for all parameters in three launches: torch.nn.utils.clip_grad_norm_ + optimizer.step() of
+ * optimize_fn (RD/losses.py:29-47: Adam / AdamW, get_optimizer :12-23) and ExponentialMovingAverage.update
+ * (RD/models/ema.py:32-52).  Tensors stay in torch's storage: a slot is the five device pointers of one
+ * parameter (ema may be NULL: no EMA for that tensor).  rdmi_opt_create copies the table; rebuild it when
+ * a pointer changes. */
+typedef struct rdmi_opt rdmi_opt;
+typedef struct {
+    float* param; float* grad; float* exp_avg; float* exp_avg_sq; float* ema;
+    unsigned long long numel;
+} rdmi_opt_slot;
+typedef struct {
+    float lr, beta1, beta2, eps, weight_decay;  /* this step's learning rate (after warm-up) etc., fp32 copies   */
+    double lr_d, beta1_d, beta2_d;              /* the same as python floats: bias corrections are formed in double */
+    int decoupled_wd;                           /* 0 Adam (L2 into the gradient), 1 AdamW                          */
+    int step;                                   /* 1-based update count t (bias correction 1 - beta^t)             */
+    float max_norm;                             /* clip_grad_norm_ max_norm; < 0 disables clipping                 */
+    double ema_decay_d;                         /* this update's min(decay, (1+n)/(10+n)); ignored where ema NULL  */
+    int write_back_grad;                        /* 1: leave the clipped gradient in grad, as clip_grad_norm_ does  */
+} rdmi_opt_hyper;
+int rdmi_opt_create(const rdmi_opt_slot* slots_host, int n_slots, rdmi_opt** out);
+/* total_norm_out: NULL or a device float receiving the pre-clip global gradient norm (clip_grad_norm_'s return). */
+int rdmi_opt_step(rdmi_opt* opt, const rdmi_opt_hyper* hyper, float* total_norm_out, void* stream);
+int rdmi_opt_destroy(rdmi_opt* opt);
+
 /* Copy an internal activation (by reference module name, e.g. "down_blocks.0", "temb") of the LAST
  * forward to dst as [B, C, H, W]; returns its C,H,W.  Debug / parity-test hook. */
 int rdmi_get_tap(rdmi_ctx* ctx, const char* name, float* dst, size_t dst_numel, int* C, int* H, int* W,

@@ -21,6 +21,7 @@
 #include "misc_kernels.h"
 #include "unet_kernel.h"
 #include "bwd_kernels.h"
+#include "opt_kernels.h"
 
 namespace {
 
@@ -1646,6 +1647,70 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
         if (c->profiling && (i % 16 == 15)) prof_collect(c);
     }
     if (c->profiling) prof_collect(c);
+    return 0;
+}
+
+// ---- multi-tensor optimizer (clip + Adam/AdamW + EMA), csrc/opt_kernels.h ---------------------------------------------
+struct rdmi_opt {
+    int nslots = 0, nchunks = 0;
+    OptSlot* d_slots = nullptr; OptChunk* d_chunks = nullptr; int* d_first = nullptr; float* d_partial = nullptr; float* d_norm = nullptr;
+};
+
+int rdmi_opt_create(const rdmi_opt_slot* slots, int n, rdmi_opt** out) {
+    if (!slots || !out || n < 1) return fail("rdmi_opt_create: null / empty slot table");
+    static_assert(sizeof(rdmi_opt_slot) == sizeof(OptSlot), "ABI slot layout");
+    std::vector<OptChunk> chunks;
+    std::vector<int> first((size_t)n + 1);
+    for (int t = 0; t < n; ++t) {
+        if (!slots[t].param || !slots[t].grad || !slots[t].exp_avg || !slots[t].exp_avg_sq) return fail("rdmi_opt_create: slot %d has a null pointer", t);
+        if (slots[t].numel >= (1ull << 32)) return fail("rdmi_opt_create: slot %d has %llu elements (>= 2^32)", t, slots[t].numel);
+        first[(size_t)t] = (int)chunks.size();
+        for (unsigned long long o = 0; o < slots[t].numel; o += OPT_CHUNK) chunks.push_back({t, (unsigned)o});
+    }
+    first[(size_t)n] = (int)chunks.size();
+    rdmi_opt* q = new rdmi_opt();
+    q->nslots = n; q->nchunks = (int)chunks.size();
+    auto bail = [&](const char* what) { rdmi_opt_destroy(q); return fail("rdmi_opt_create: %s failed", what); };
+    if (hipMalloc((void**)&q->d_slots, (size_t)n * sizeof(OptSlot)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void**)&q->d_chunks, std::max<size_t>(chunks.size(), 1) * sizeof(OptChunk)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void**)&q->d_first, ((size_t)n + 1) * sizeof(int)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void**)&q->d_partial, std::max<size_t>(chunks.size(), 1) * sizeof(float)) != hipSuccess) return bail("hipMalloc");
+    if (hipMalloc((void**)&q->d_norm, 2 * sizeof(float)) != hipSuccess) return bail("hipMalloc");
+    if (hipMemcpy(q->d_slots, slots, (size_t)n * sizeof(OptSlot), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    if (hipMemcpy(q->d_chunks, chunks.data(), chunks.size() * sizeof(OptChunk), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    if (hipMemcpy(q->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    *out = q;
+    return 0;
+}
+
+int rdmi_opt_destroy(rdmi_opt* q) {
+    if (!q) return 0;
+    for (void* p : {(void*)q->d_slots, (void*)q->d_chunks, (void*)q->d_first, (void*)q->d_partial, (void*)q->d_norm}) if (p) (void)hipFree(p);
+    delete q;
+    return 0;
+}
+
+int rdmi_opt_step(rdmi_opt* q, const rdmi_opt_hyper* hy, float* total_norm_out, void* stream) {
+    if (!q || !hy) return fail("rdmi_opt_step: null argument");
+    if (hy->step < 1) return fail("rdmi_opt_step: step=%d (the first update is step 1)", hy->step);
+    hipStream_t s = (hipStream_t)stream;
+    OptHyper h{};
+    h.lr = hy->lr; h.beta1 = hy->beta1; h.beta2 = hy->beta2; h.eps = hy->eps; h.weight_decay = hy->weight_decay; h.decoupled_wd = hy->decoupled_wd;
+    // python-float arithmetic of torch.optim.adam._single_tensor_adam, rounded to fp32 where the kernel consumes it
+    const double bc1 = 1.0 - std::pow((double)hy->beta1_d, (double)hy->step), bc2 = 1.0 - std::pow((double)hy->beta2_d, (double)hy->step);
+    h.step_size = (float)((double)hy->lr_d / bc1);
+    h.bc2_sqrt = (float)std::sqrt(bc2);
+    h.one_minus_beta1 = (float)(1.0 - hy->beta1_d); h.one_minus_beta2 = (float)(1.0 - hy->beta2_d);
+    h.max_norm = hy->max_norm;
+    h.one_minus_ema_decay = (float)(1.0 - hy->ema_decay_d);
+    h.write_back_grad = hy->write_back_grad;
+    hipLaunchKernelGGL(opt_sumsq_kernel, dim3((unsigned)q->nchunks), dim3(RDMI_THREADS), 16, s, (const OptSlot*)q->d_slots, (const OptChunk*)q->d_chunks, q->d_partial);
+    hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(RDMI_THREADS), RDMI_THREADS * sizeof(float), s, (const float*)q->d_partial, (const int*)q->d_first, q->nslots,
+                       hy->max_norm, q->d_norm);
+    hipLaunchKernelGGL(opt_adam_ema_kernel, dim3((unsigned)q->nchunks), dim3(RDMI_THREADS), 0, s, (const OptSlot*)q->d_slots, (const OptChunk*)q->d_chunks, h,
+                       (const float*)q->d_norm);
+    HIP_OK(hipGetLastError());
+    if (total_norm_out) HIP_OK(hipMemcpyAsync(total_norm_out, q->d_norm, sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 

@@ -24,6 +24,23 @@
 #ifndef UW_PF_N1
 #define UW_PF_N1 4
 #endif
+#ifndef UW_PRIO
+#define UW_PRIO 0
+#endif
+#ifndef UW_LIGHT_BARRIER
+#define UW_LIGHT_BARRIER 0
+#endif
+
+// Workgroup barrier between two phases that exchange data through LDS only: wait for this wave's LDS operations, then
+// s_barrier.  __syncthreads() additionally drains every outstanding global load (s_waitcnt vmcnt(0)) -- the op-descriptor,
+// GroupNorm-parameter and weight prefetches that are deliberately left in flight across op boundaries.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__) && UW_LIGHT_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 
 enum { FOP_GATHER = 0, FOP_STORE = 1, FOP_GN = 2, FOP_CONV = 3, FOP_ATTN = 4 };
 
@@ -243,7 +260,7 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
     const int rstep = (UW_THREADS * mg_c4n) >> 16;      // floor(512 / c4n)
     const int r0 = (tid * mg_c4n) >> 16, c = (tid - r0 * c4n) << 2;
     const bool active = r0 < rstep;
-    __syncthreads();
+    lds_barrier();
     if (active && !(dbg & 128)) {
         f32x4 mu, rstd;
         for (int j = 0; j < 4; ++j) { const int gg = ((c + j) * mg_Cg) >> 16; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
@@ -607,7 +624,7 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
         }
     }
     if (fused_gn) {
-        __syncthreads();
+        lds_barrier();
         if (k_nmt > 0) fconv_gn_apply(w, k_mt0, WM, k_nt, k_nmt, lane, gmul, gadd, acc);
     }
 }
@@ -670,7 +687,7 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- O = P V: 4 channel tiles x mtiles row tiles over 8 waves (wave = (row half, channel tile))
     {
         const int wn = wave & 3, wm = wave >> 2;
@@ -720,6 +737,11 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         float* z = lds_f(u.zero_off);
         for (int i = tid; i < (u.zero_bytes >> 2); i += UW_THREADS) z[i] = 0.f;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && UW_PRIO == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the second-dispatched half loses every arbitration otherwise (MI355X_MICROARCH.md)
+#elif defined(__HIP_DEVICE_COMPILE__) && UW_PRIO == 2
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
     if (DIAG && u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
     // descriptors are kept TWO ops ahead (cur, nxt resident; the load for pc+2 is in flight) so that small operands
@@ -745,7 +767,10 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             default: break;
         }
-        __syncthreads();
+        // ops that stored to global memory (skip spills, the network output) end with the full barrier: their stores must have
+        // completed before a later op of ANOTHER wave reads them back; everything else hands over through LDS only
+        if (kind == FOP_STORE || (kind == FOP_CONV && OPI(cur, dst_kind) == 2)) __syncthreads();
+        else lds_barrier();
         if (DIAG && u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
         cur = nxt; nxt = nn; pgm = ngm; pbt = nbt;
     }

@@ -32,6 +32,17 @@ class PcOpts(C.Structure):
                 ('seed', C.c_uint64), ('seq_offset', C.c_uint64)]
 
 
+class OptSlot(C.Structure):
+    _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
+                ('ema', C.c_void_p), ('numel', C.c_ulonglong)]
+
+
+class OptHyper(C.Structure):
+    _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('weight_decay', C.c_float),
+                ('lr_d', C.c_double), ('beta1_d', C.c_double), ('beta2_d', C.c_double), ('decoupled_wd', C.c_int),
+                ('step', C.c_int), ('max_norm', C.c_float), ('ema_decay_d', C.c_double), ('write_back_grad', C.c_int)]
+
+
 _F = C.c_void_p   # device float* travel as integers (tensor.data_ptr())
 _PROTOS = {
     'rdmi_create': ([C.POINTER(Arch), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)], C.c_int),
@@ -55,6 +66,9 @@ _PROTOS = {
     'rdmi_em_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
     'rdmi_langevin_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_pc_sample': ([C.c_void_p, _F, _F, _F, _F, _F, _F, C.c_int, C.POINTER(PcOpts), C.c_uint, C.c_void_p], C.c_int),
+    'rdmi_opt_create': ([C.POINTER(OptSlot), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    'rdmi_opt_step': ([C.c_void_p, C.POINTER(OptHyper), _F, C.c_void_p], C.c_int),
+    'rdmi_opt_destroy': ([C.c_void_p], C.c_int),
     'rdmi_get_tap': ([C.c_void_p, C.c_char_p, _F, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                       C.POINTER(C.c_int), C.c_void_p], C.c_int),
     'rdmi_set_profiling': ([C.c_void_p, C.c_int], C.c_int),
@@ -228,6 +242,47 @@ class Context:
             out.append(dict(kernel=nm.value.decode(), ms=ms.value, launches=n.value, flops=fl.value))
             i += 1
         return out
+
+
+class OptPlan:
+    """One rdmi_opt: the device pointer table of a parameter list (param, grad, exp_avg, exp_avg_sq[, ema shadow])."""
+
+    def __init__(self, params, grads, exp_avgs, exp_avg_sqs, emas, device):
+        self.device = torch.device(device)
+        self.ptrs = tuple(t.data_ptr() for ts in (params, grads, exp_avgs, exp_avg_sqs, emas or ()) for t in ts)
+        n = len(params)
+        tab = (OptSlot * n)()
+        for i in range(n):
+            for t in (params[i], grads[i], exp_avgs[i], exp_avg_sqs[i]) + ((emas[i],) if emas else ()):
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params[i].numel()
+                require_device(t)
+            tab[i].param, tab[i].grad = params[i].data_ptr(), grads[i].data_ptr()
+            tab[i].exp_avg, tab[i].exp_avg_sq = exp_avgs[i].data_ptr(), exp_avg_sqs[i].data_ptr()
+            tab[i].ema = emas[i].data_ptr() if emas else None
+            tab[i].numel = params[i].numel()
+        self._h = C.c_void_p()
+        self._owner = lib()
+        with self._guard():
+            check(lib().rdmi_opt_create(tab, n, C.byref(self._h)))
+        self._stream_of = params[0]
+
+    def _guard(self):
+        return torch.cuda.device(self.device) if self.device.type == 'cuda' else _Null()
+
+    def step(self, hyper, total_norm_out=None):
+        with self._guard():
+            check(self._owner.rdmi_opt_step(self._h, C.byref(hyper), ptr(total_norm_out), stream_of(self._stream_of)))
+
+    def close(self):
+        if self._h:
+            self._owner.rdmi_opt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _Null:

@@ -17,12 +17,18 @@ class ExponentialMovingAverage:
         self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
         self.collected_params = []
 
-    def update(self, parameters):
-        """s -= (1 - d) * (s - p),  d = min(decay, (1 + n) / (10 + n))   (RD/models/ema.py:32-52)."""
+    def next_decay(self):
+        """Advance the update counter and return this update's decay min(decay, (1 + n) / (10 + n))   (RD/models/ema.py:43-46).
+        Used by update() and by the fused optimizer step (rdmi.losses), which applies the shadow update in its own kernel."""
         decay = self.decay
         if self.num_updates is not None:
             self.num_updates += 1
             decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        return decay
+
+    def update(self, parameters):
+        """s -= (1 - d) * (s - p),  d = min(decay, (1 + n) / (10 + n))   (RD/models/ema.py:32-52)."""
+        decay = self.next_decay()
         with torch.no_grad():
             params = [p.detach() for p in parameters if p.requires_grad]
             diff = torch._foreach_sub(self.shadow_params, params)

@@ -340,3 +340,54 @@ def test_optimizer_and_ema_updates_match_reference(env, golden):
     g = golden('train_step_w0.npz')
     out = _train_steps_w0(env['ge'], 'cpu', g, 2)
     check_train_w0_against_reference(out, g, 2)
+
+
+def test_fused_optimizer_step_equals_torch(emu):
+    check_fused_optimizer_step_equals_torch('cpu')
+
+
+def check_fused_optimizer_step_equals_torch(dev):
+    """rdmi_opt_step (clip + Adam/AdamW + EMA in three launches) against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(W)
+    .step() + the reference-shaped EMA loop on the same tensors (ragged sizes, a tensor larger than one chunk, weight decay,
+    several steps so the moments and bias corrections matter); state_dict round-trips with torch.optim.Adam."""
+    from rdmi import losses
+    from rdmi.models.ema import ExponentialMovingAverage
+    from types import SimpleNamespace as NS
+    for name, wd in (('Adam', 0.0), ('AdamW', 0.01), ('Adam', 0.02)):
+        g = torch.Generator().manual_seed(5)
+        shapes = [(3,), (17, 5), (4100,), (64, 9, 9), (1,)]
+        pa = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        cfg = NS(optim=NS(optimizer=name, lr=3e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=wd, warmup=4, grad_clip=0.7))
+        oa = losses.get_optimizer(cfg, pa)
+        assert isinstance(oa, losses._FusedStep) and isinstance(oa, torch.optim.Adam if name == 'Adam' else torch.optim.AdamW)
+        ob = (torch.optim.Adam if name == 'Adam' else torch.optim.AdamW)(pb, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        ea, eb = ExponentialMovingAverage(pa, 0.999), ExponentialMovingAverage(pb, 0.999)
+        fn = losses.optimization_manager(cfg)
+        for step in range(5):
+            grads = [(torch.randn(*s, generator=g) * (3.0 if step % 2 else 0.01)).to(dev) for s in shapes]     # clipped and unclipped steps
+            for p, q, gr in zip(pa, pb, grads):
+                p.grad, q.grad = gr.clone(), gr.clone()
+            assert fn(oa, pa, step=step, ema=ea) is True
+            for grp in ob.param_groups:
+                grp['lr'] = 3e-3 * min(step / 4, 1.0)
+            torch.nn.utils.clip_grad_norm_(pb, max_norm=0.7)
+            ob.step()
+            eb.update(pb)
+            for p, q in zip(pa, pb):
+                np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=2e-6, atol=0)        # the clipped gradient is left in .grad
+                np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=3e-7)
+            for s, t in zip(ea.shadow_params, eb.shadow_params):
+                np.testing.assert_allclose(s.cpu().numpy(), t.cpu().numpy(), rtol=2e-6, atol=3e-7)
+        assert ea.num_updates == eb.num_updates == 5
+        sd = oa.state_dict()
+        assert int(sd['state'][0]['step']) == 5 and set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+        import copy                                              # (load_state_dict keeps same-dtype tensors by reference: copy, as a checkpoint file would)
+        ob.load_state_dict(copy.deepcopy(sd))                    # a torch.optim.Adam accepts the fused optimizer's checkpoint
+        oa.load_state_dict(copy.deepcopy(ob.state_dict()))       # and the other way round; the next fused step re-binds the pointers
+        for p, q in zip(pa, pb):
+            p.grad, q.grad = torch.ones_like(p), torch.ones_like(q)
+        fn(oa, pa, step=5, ema=None)
+        torch.nn.utils.clip_grad_norm_(pb, max_norm=0.7); ob.step()
+        for p, q in zip(pa, pb):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=3e-7)

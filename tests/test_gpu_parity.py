@@ -367,6 +367,13 @@ def test_optimizer_and_ema_updates_match_reference(env, golden):
     check_train_w0_against_reference(out, g, 3)
 
 
+def test_fused_optimizer_step_equals_torch(env):
+    """The multi-tensor HIP optimizer step (clip + Adam/AdamW + EMA) against torch's own clip_grad_norm_ / Adam(W).step() and the
+    reference-shaped EMA loop on the same device tensors."""
+    from tests.test_emu_parity import check_fused_optimizer_step_equals_torch
+    check_fused_optimizer_step_equals_torch(env['dev'])
+
+
 def test_dropout_and_label_drop_train_mode(env):
     """Train mode with the shipped dropout=0.2 / cond_drop_prob=0.5: finite loss and gradients, the dropout mask is a
     function of the step seed (same torch seed -> identical loss/gradients, different seed -> different), and a
