@@ -317,8 +317,25 @@ def gen_gto():
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         a, th, u = ns['_convert_to_spherical'](stub, u3[..., 0].copy(), u3[..., 1].copy(), u3[..., 2].copy())
+    # The whole un-normalisation (affine columns included) is an inline block of generate_samples (:254-328) that cannot be
+    # imported (omegaconf): its statements are compiled from the file's AST in memory -- the statements from
+    # `samples = all_samples.reshape(...)` to `samples = np.column_stack(...)` -- and executed on a synthetic all_samples with
+    # a stub `self` that carries the compiled _convert_to_spherical.  Nothing of the reference is written to disk but the arrays.
+    gs = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == 'generate_samples')
+    body = [st for st in gs.body if 254 <= st.lineno <= 328 and not (isinstance(st, ast.Expr) and isinstance(st.value, ast.Call)
+                                                                       and getattr(st.value.func, 'id', '') == 'print')]
+    assert isinstance(body[0], ast.Assign) and body[0].targets[0].id == 'samples' and body[-1].targets[0].id == 'samples', 'block moved'
+    rng2 = np.random.RandomState(9)
+    all_samples = (rng2.rand(48, 1, 9, 9).astype(np.float32) * 1.3 - 0.15)          # sampler output lives in [0,1]; go a bit outside
+    stub2 = NS(total_spherical_clips=0, total_spherical_elements=0)
+    stub2._convert_to_spherical = lambda ux, uy, uz: ns['_convert_to_spherical'](stub2, ux, uy, uz)
+    env2 = {'np': np, 'self': stub2, 'all_samples': all_samples.copy()}
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'), env2)
+    assert env2['samples'].shape == (48, 67)
     save('gto_unnormalize.npz', ux=u3[..., 0], uy=u3[..., 1], uz=u3[..., 2], alpha=a, theta=th, u=u,
-         clips=np.int64(stub.total_spherical_clips))
+         clips=np.int64(stub.total_spherical_clips), full_in=all_samples, full_out=env2['samples'].astype(np.float64),
+         full_clips=np.int64(stub2.total_spherical_clips))
 
 
 def gen_gto_dataset():

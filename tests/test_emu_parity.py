@@ -140,6 +140,20 @@ def test_gto_unnormalize(emu, golden):
     np.testing.assert_allclose(out.numpy()[:, :4], ref[:, :4], rtol=2e-6, atol=1e-6)
     np.testing.assert_allclose(out.numpy()[:, 64:], ref[:, 64:], rtol=2e-6, atol=1e-6)
     assert abs(int(clips.item()) - rclips) <= 2                          # |u| within an ulp of 1 may flip
+    # all 67 columns against the reference's own inline block (fixture full_in/full_out, recorded by exec-ing its AST)
+    fo = harness.unnormalize_gto(T(g['full_in']))[0].numpy()
+    _check_gto_full(fo, g['full_out'])
+
+
+def _check_gto_full(out, ref):
+    """out [N,67] (HIP) vs the reference block's float64 output: affine columns 2e-6 relative (fp32 vs float64-of-fp32 inputs),
+    angles 5e-5 rad (libm asinf/atan2f), modulo the 0 / 2pi wrap."""
+    ang = np.zeros(67, bool)
+    for t in range(20):
+        ang[4 + 3 * t] = ang[5 + 3 * t] = True
+    np.testing.assert_allclose(out[:, ~ang], ref[:, ~ang], rtol=2e-6, atol=1e-6)
+    d = np.abs(out[:, ang] - ref[:, ang])
+    assert np.all(np.minimum(d, np.abs(d - 2 * np.pi)) < 5e-5)
 
 
 @pytest.mark.parametrize('corr', ['none', 'langevin'])

@@ -469,6 +469,8 @@ def test_gto_unnormalize(env, golden):
     np.testing.assert_allclose(out[:, :4], ref[:, :4], rtol=2e-6, atol=1e-6)
     np.testing.assert_allclose(out[:, 64:], ref[:, 64:], rtol=2e-6, atol=1e-6)
     assert abs(int(clips.item()) - rclips) <= 2
+    from tests.test_emu_parity import _check_gto_full
+    _check_gto_full(harness.unnormalize_gto(T(g['full_in'], dev))[0].cpu().numpy(), g['full_out'])
     # full size: 100k samples, every magnitude <= 1, angles in [0, 2pi), ragged N, empty input
     big = torch.rand(100003, 1, 9, 9, device=dev)
     o2, c2 = harness.unnormalize_gto(big)

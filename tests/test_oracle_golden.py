@@ -152,3 +152,12 @@ def test_gto_dataset_item_matches_reference_class(golden):
         img, lab = O.gto_image_item(g['data'][i])
         assert np.array_equal(img.reshape(1, 9, 9), g['images'][i]) and np.array_equal(lab, g['labels'][i])
 
+
+
+def test_gto_unnormalize_all_columns_against_reference_block(golden):
+    """N1: the oracle's un-normalisation against the output of the reference's own inline block
+    (Benchmark/gto_halo_benchmarking.py:254-328, executed from its AST by oracle/gen_golden.py) -- all 67 columns, bit for bit."""
+    from oracle import rd_oracle as O
+    g = golden('gto_unnormalize.npz')
+    ref, clips = O.gto_unnormalize(g['full_in'].reshape(g['full_in'].shape[0], -1))
+    assert np.array_equal(ref, g['full_out']) and clips == int(g['full_clips'])
