@@ -165,6 +165,27 @@ int rdmi_pc_sample(rdmi_ctx* ctx, float* x, const float* labels, const float* we
                    float* trace, const float* teacher, int B, const rdmi_pc_opts* opts, unsigned flags,
                    void* stream);
 
+/* ---- probability-flow ODE sampler ------------------------------------------------------------
+ * Replaces get_ode_sampler's ode_sampler (RD/sampling.py:342-392): scipy.integrate.solve_ivp(method='RK45') over
+ * drift_fn(score_fn, x, t) * bump(x), integrated from T to eps with the adaptive Dormand-Prince 5(4) scheme.  State, stages,
+ * stage combinations, the error norm and the score network all stay on the device (float64 state like scipy, float32
+ * right-hand side like the reference); the host carries only the scalar step controller.  SYNCHRONOUS (the controller
+ * reads one scalar per attempted step), like the scipy loop it replaces. */
+typedef struct {
+    double T, eps;             /* integrate t from T down to eps (sde.T, sampler eps)                     */
+    double rtol, atol;         /* solve_ivp tolerances (reference: 1e-5, 1e-5)                            */
+    double sigma_min, sigma_max;
+    float moll;                /* bump mollifier strength (config.sampling.moll); <= 0: bump(x) = x       */
+    int use_cfg;               /* 1: class_labels given -> classifier-free-guidance score (2B forward)    */
+    double first_step;         /* > 0: initial |h| (solve_ivp first_step); 0: scipy's select_initial_step */
+    int max_steps;             /* > 0: stop after this many accepted steps (parity tests); 0: run to eps  */
+    double* h_next_out;        /* NULL or host double receiving the controller's next |h|                 */
+} rdmi_ode_opts;
+/* x: in = the initial state (the reference's (1-2 side_eps) U[0,1] + side_eps draw, or z), out = y(eps) as float32.
+ * nfev_out: number of right-hand-side evaluations (solution.nfev).  t_final: NULL or host double, the time reached. */
+int rdmi_ode_sample(rdmi_ctx* ctx, float* x, const float* labels, const float* weight, int B, const rdmi_ode_opts* opts,
+                    int* nfev_out, double* t_final, unsigned flags, void* stream);
+
 /* ---- multi-tensor optimizer step -------------------------------------------------------------
  * Replaces, for all parameters in three launches: torch.nn.utils.clip_grad_norm_ + optimizer.step() of
  * optimize_fn (RD/losses.py:29-47: Adam / AdamW, get_optimizer :12-23) and ExponentialMovingAverage.update

@@ -22,6 +22,7 @@
 #include "unet_kernel.h"
 #include "bwd_kernels.h"
 #include "opt_kernels.h"
+#include "ode_kernels.h"
 
 namespace {
 
@@ -1646,6 +1647,128 @@ int rdmi_pc_sample(rdmi_ctx* c, float* x, const float* labels, const float* weig
         HIP_OK(hipGetLastError());
         if (c->profiling && (i % 16 == 15)) prof_collect(c);
     }
+    if (c->profiling) prof_collect(c);
+    return 0;
+}
+
+// ---- probability-flow ODE sampler: scipy's RK45 (Dormand-Prince 5(4), scipy/integrate/_ivp/rk.py) with the state on the device ----
+int rdmi_ode_sample(rdmi_ctx* c, float* x, const float* labels, const float* weight, int B, const rdmi_ode_opts* o, int* nfev_out,
+                    double* t_final, unsigned flags, void* stream) {
+    if (!c || !x || !o) return fail("null argument");
+    const int NBm = o->use_cfg ? 2 * B : B;
+    if (NBm > c->max_batch) return fail("model batch %d > max_batch=%d", NBm, c->max_batch);
+    if (o->use_cfg && !labels) return fail("use_cfg=1 needs class_labels");
+    if (!(o->rtol > 0) || !(o->atol > 0)) return fail("rtol / atol must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = maybe_repack(c, flags, s)) return e;
+    const int E = c->H * c->W * c->arch.channels;
+    const long n = (long)B * E;
+    const unsigned gn = (unsigned)ceil_div((int)n, RDMI_THREADS);
+    const float smin = (float)o->sigma_min, ratio = (float)(o->sigma_max / o->sigma_min), gc = g_const(o->sigma_min, o->sigma_max);
+    // Dormand-Prince tableau as scipy holds it (rk.py: class RK45)
+    static const double Cc[6] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1};
+    static const double A[6][5] = {{0, 0, 0, 0, 0}, {1.0 / 5, 0, 0, 0, 0}, {3.0 / 40, 9.0 / 40, 0, 0, 0}, {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+                                   {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+                                   {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+    static const double Bc[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+    static const double Ec[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+    const double SAFETY = 0.9, MIN_FACTOR = 0.2, MAX_FACTOR = 10, err_exp = -1.0 / 5;
+    double *d_y = nullptr, *d_ynew = nullptr, *d_K = nullptr, *d_f1 = nullptr, *d_red = nullptr;
+    float* d_x32 = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)d_y, (void*)d_ynew, (void*)d_K, (void*)d_f1, (void*)d_red, (void*)d_x32}) if (p) (void)hipFree(p); };
+#define ODE_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail("%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    ODE_OK(hipMalloc((void**)&d_y, n * sizeof(double)));
+    ODE_OK(hipMalloc((void**)&d_ynew, n * sizeof(double)));
+    ODE_OK(hipMalloc((void**)&d_K, 7 * n * sizeof(double)));
+    ODE_OK(hipMalloc((void**)&d_f1, n * sizeof(double)));
+    ODE_OK(hipMalloc((void**)&d_red, 4 * sizeof(double)));
+    ODE_OK(hipMalloc((void**)&d_x32, n * sizeof(float)));
+    int nfev = 0;
+    // fun(t, x32) -> Kout (float64 copy of the float32 drift * bump)
+    auto fun = [&](double t, double* Kout) -> int {
+        FwdIn f{d_x32, o->use_cfg ? B : 0, nullptr, 0, (float)t, 1, smin, ratio, labels, B, c->d_s2, NBm};     // vec_t = ones(B) * t  (float32)
+        if (int e = run_forward(c, f, s)) return e;
+        hipLaunchKernelGGL(ode_rhs_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const float*)c->d_s2, weight, (const float*)d_x32, Kout, B, E, (float)t, smin, ratio, gc,
+                           o->use_cfg, o->moll);
+        ++nfev;
+        return 0;
+    };
+    auto norm_of = [&](int mode, const double* a, const double* b, const double* y0, double h, double* out_host) -> int {
+        OdeNormArgs q{a, b, y0, d_K, n, mode, o->atol, o->rtol, h, {Ec[0], Ec[1], Ec[2], Ec[3], Ec[4], Ec[5], Ec[6]}, d_red, 0};
+        hipLaunchKernelGGL(ode_norm_kernel, dim3(1), dim3(RDMI_THREADS), RDMI_THREADS * sizeof(double), s, q);
+        double ss = 0;
+        if (hipMemcpyAsync(&ss, d_red, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return fail("ode: read-back failed");
+        *out_host = std::sqrt(ss) / std::sqrt((double)n);            // scipy: norm(x) = ||x|| / sqrt(x.size)
+        return 0;
+    };
+    const double t0 = o->T, t_bound = o->eps, direction = t_bound >= t0 ? 1.0 : -1.0;
+    double t = t0;
+    int rc = 0;
+    hipLaunchKernelGGL(ode_f2d_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const float*)x, d_y, n);
+    hipLaunchKernelGGL(ode_stage_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const double*)d_y, (const double*)d_K, n, 0, 0., 0., 0., 0., 0., 0., 0., (double*)nullptr, d_x32);
+    if ((rc = fun(t, d_K))) { cleanup(); return rc; }                // self.f = fun(t0, y0)
+    double h_abs;
+    if (o->first_step > 0) h_abs = o->first_step;
+    else {   // select_initial_step (scipy/integrate/_ivp/common.py), order = 4
+        const double interval = std::fabs(t_bound - t0);
+        double d0 = 0, d1 = 0, d2 = 0;
+        if ((rc = norm_of(0, d_y, nullptr, d_y, 0, &d0)) || (rc = norm_of(0, d_K, nullptr, d_y, 0, &d1))) { cleanup(); return rc; }
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = std::min(h0, interval);
+        hipLaunchKernelGGL(ode_axpy_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const double*)d_y, (const double*)d_K, h0 * direction, n, d_x32);
+        if ((rc = fun(t0 + h0 * direction, d_f1))) { cleanup(); return rc; }
+        if ((rc = norm_of(1, d_f1, d_K, d_y, 0, &d2))) { cleanup(); return rc; }
+        d2 /= h0;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 1.0 / 5);
+        h_abs = std::min(std::min(100 * h0, h1), interval);
+    }
+    int steps = 0;
+    while (direction * (t - t_bound) < 0) {
+        if (o->max_steps > 0 && steps >= o->max_steps) break;
+        const double min_step = 10 * std::fabs(std::nextafter(t, direction * INFINITY) - t);
+        if (h_abs < min_step) h_abs = min_step;
+        bool accepted = false, rejected = false;
+        double t_new = t, h = 0;
+        while (!accepted) {
+            if (h_abs < min_step) { cleanup(); return fail("ode: required step size is less than spacing between numbers (scipy: TOO_SMALL_STEP) at t=%g", t); }
+            h = h_abs * direction;
+            t_new = t + h;
+            if (direction * (t_new - t_bound) > 0) t_new = t_bound;
+            h = t_new - t;
+            h_abs = std::fabs(h);
+            for (int st = 1; st < 6; ++st) {                         // rk_step: K[s] = fun(t + c_s h, y + h * K[:s].T a_s[:s])
+                hipLaunchKernelGGL(ode_stage_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const double*)d_y, (const double*)d_K, n, st, A[st][0], A[st][1], A[st][2], A[st][3],
+                                   A[st][4], 0., h, (double*)nullptr, d_x32);
+                if ((rc = fun(t + Cc[st] * h, d_K + (size_t)st * n))) { cleanup(); return rc; }
+            }
+            hipLaunchKernelGGL(ode_stage_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const double*)d_y, (const double*)d_K, n, 6, Bc[0], Bc[1], Bc[2], Bc[3], Bc[4], Bc[5], h,
+                               d_ynew, d_x32);                       // y_new = y + h * K[:-1].T B
+            if ((rc = fun(t + h, d_K + (size_t)6 * n))) { cleanup(); return rc; }      // f_new -> K[-1]
+            double err = 0;
+            if ((rc = norm_of(2, nullptr, d_ynew, d_y, h, &err))) { cleanup(); return rc; }
+            if (err < 1) {
+                double factor = err == 0 ? MAX_FACTOR : std::min(MAX_FACTOR, SAFETY * std::pow(err, err_exp));
+                if (rejected) factor = std::min(1.0, factor);
+                h_abs *= factor;
+                accepted = true;
+            } else {
+                h_abs *= std::max(MIN_FACTOR, SAFETY * std::pow(err, err_exp));
+                rejected = true;
+            }
+        }
+        // accept: y <- y_new, f <- f_new (K[0] <- K[6])
+        std::swap(d_y, d_ynew);
+        ODE_OK(hipMemcpyAsync(d_K, d_K + (size_t)6 * n, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        t = t_new;
+        ++steps;
+    }
+    hipLaunchKernelGGL(ode_d2f_kernel, dim3(gn), dim3(RDMI_THREADS), 0, s, (const double*)d_y, x, n);
+    ODE_OK(hipStreamSynchronize(s));
+    if (nfev_out) *nfev_out = nfev;
+    if (t_final) *t_final = t;
+    if (o->h_next_out) *o->h_next_out = h_abs;
+    cleanup();
+#undef ODE_OK
     if (c->profiling) prof_collect(c);
     return 0;
 }

@@ -32,6 +32,12 @@ class PcOpts(C.Structure):
                 ('seed', C.c_uint64), ('seq_offset', C.c_uint64)]
 
 
+class OdeOpts(C.Structure):
+    _fields_ = [('T', C.c_double), ('eps', C.c_double), ('rtol', C.c_double), ('atol', C.c_double), ('sigma_min', C.c_double),
+                ('sigma_max', C.c_double), ('moll', C.c_float), ('use_cfg', C.c_int), ('first_step', C.c_double),
+                ('max_steps', C.c_int), ('h_next_out', C.POINTER(C.c_double))]
+
+
 class OptSlot(C.Structure):
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
                 ('ema', C.c_void_p), ('numel', C.c_ulonglong)]
@@ -66,6 +72,7 @@ _PROTOS = {
     'rdmi_em_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
     'rdmi_langevin_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_pc_sample': ([C.c_void_p, _F, _F, _F, _F, _F, _F, C.c_int, C.POINTER(PcOpts), C.c_uint, C.c_void_p], C.c_int),
+    'rdmi_ode_sample': ([C.c_void_p, _F, _F, _F, C.c_int, C.POINTER(OdeOpts), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint, C.c_void_p], C.c_int),
     'rdmi_opt_create': ([C.POINTER(OptSlot), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
     'rdmi_opt_step': ([C.c_void_p, C.POINTER(OptHyper), _F, C.c_void_p], C.c_int),
     'rdmi_opt_destroy': ([C.c_void_p], C.c_int),
@@ -210,6 +217,15 @@ class Context:
         with self._guard():
             check(lib().rdmi_pc_sample(self._h, ptr(x), ptr(labels), ptr(weight), ptr(noise), ptr(trace), ptr(teacher),
                                        x.shape[0], C.byref(opts), flags, stream_of(x)))
+
+    def ode_sample(self, x, labels, weight, opts, flags=0):
+        """-> (nfev, t reached, next |h|); x is updated in place."""
+        nfev, tfin, hn = C.c_int(), C.c_double(), C.c_double()
+        opts.h_next_out = C.pointer(hn)
+        with self._guard():
+            check(lib().rdmi_ode_sample(self._h, ptr(x), ptr(labels), ptr(weight), x.shape[0], C.byref(opts), C.byref(nfev), C.byref(tfin),
+                                        flags, stream_of(x)))
+        return nfev.value, tfin.value, hn.value
 
     def get_tap(self, name, like, nb):
         c, h, w = C.c_int(), C.c_int(), C.c_int()

@@ -254,9 +254,16 @@ def _fused_pc(sde, model, x, class_labels, weight, langevin, snr, n_steps, eps, 
     return x
 
 
-def get_ode_sampler(sde, shape, rtol=1e-5, atol=1e-5, method='RK45', eps=1e-3, moll=200, side_eps=1e-2, device='cuda'):
-    """Probability-flow ODE sampler with scipy's black-box RK45 (RD/sampling.py:342-392).  Host-driven like the
-    reference (each RHS evaluation is one HIP score call); kept so `method: ode` configs keep dispatching."""
+def get_ode_sampler(sde, shape, rtol=1e-5, atol=1e-5, method='RK45', eps=1e-3, moll=200, side_eps=1e-2, device='cuda',
+                    fused=True, first_step=0.0, max_steps=0):
+    """Probability-flow ODE sampler (RD/sampling.py:342-392): solve_ivp(method='RK45') over drift_fn * bump from sde.T to eps.
+
+    Two routes:
+      * DEVICE (native NCSNpp, RVESDE, method RK45): rdmi_ode_sample -- scipy's adaptive Dormand-Prince 5(4) with the float64
+        state, the stage combinations, the error norm and the score network all on the GPU; the host keeps the scalar step
+        controller.  Same (x, nfev) contract as the reference.
+      * GENERIC (any other model / SDE / method, or fused=False): the reference's scipy loop, each right-hand side one score call.
+    Extra keywords (not in the reference) are parity-test hooks: first_step (solve_ivp's first_step), max_steps."""
     from scipy import integrate
 
     def drift_fn(score_fn, x, t):
@@ -266,6 +273,22 @@ def get_ode_sampler(sde, shape, rtol=1e-5, atol=1e-5, method='RK45', eps=1e-3, m
     def ode_sampler(model, z=None, noise_removal_model=None, weight=0, class_labels=None):
         with torch.no_grad():
             x = (1 - 2 * side_eps) * torch.rand(shape).to(device) + side_eps if z is None else z
+            native, inner = mutils._is_native(model)
+            if fused and native and hasattr(sde, 'sigma_min') and method == 'RK45':
+                model.eval()
+                x = inner._prep(x).clone()
+                B = x.shape[0]
+                use_cfg = class_labels is not None
+                ctx = inner.native_context(2 * B if use_cfg else B, x.shape[2], x.shape[3], x.device)
+                o = _native.OdeOpts()
+                o.T, o.eps, o.rtol, o.atol = float(sde.T), float(eps), float(rtol), float(atol)
+                o.sigma_min, o.sigma_max, o.moll = float(sde.sigma_min), float(sde.sigma_max), float(moll)
+                o.use_cfg, o.first_step, o.max_steps = int(use_cfg), float(first_step), int(max_steps)
+                lab = class_labels.to(x.device).contiguous().float() if use_cfg else None
+                w = mutils._weight_tensor(weight, B, x.device).reshape(-1).contiguous().float() if use_cfg else None
+                nfev, t_end, h_next = ctx.ode_sample(x, lab, w, o)
+                ode_sampler.last = dict(t=t_end, h_next=h_next)          # where the controller stopped (max_steps hook)
+                return x, nfev
             if class_labels is None:
                 score_fn = mutils.get_score_fn(sde, model, train=False)
             else:

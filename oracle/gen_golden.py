@@ -283,6 +283,42 @@ def gen_train_w0():
     save('train_step_w0.npz', **out)
 
 
+def gen_ode():
+    """the reference's probability-flow ODE sampler (RD/sampling.py:342-392, scipy RK45) on an injected prior.
+    RVESDE(0.01, 0.5): with the shipped sigma_max=5 and these synthetic (untrained) weights the flow is chaotic -- the
+    reference itself needs 5390 right-hand sides and leaves the cube -- so no two fp32 implementations could be compared;
+    at sigma_max=0.5 (g(1)^2 = 2) it takes ~60 steps.  Recorded: prior, labels, final sample, nfev, every accepted time, and
+    the float64 state at a few accepted steps (for one-step parity: restart from (t_k, y_k) with first_step = |t_k+1 - t_k|)."""
+    from scipy import integrate as _integ
+    cfg = make_cfg()
+    model, _ = ref_model(cfg)
+    sde = sde_lib.RVESDE(0.01, 0.5, N=1000)
+    out = {}
+    for tag, B in (('b4', 4), ('b1', 1)):
+        g = torch.Generator().manual_seed(21 + B)
+        z = (1 - 2e-2) * torch.rand(B, 1, 9, 9, generator=g) + 1e-2
+        lab = torch.rand(B, 1, generator=g)
+        fn = sampling.get_ode_sampler(sde, (B, 1, 9, 9), eps=1e-3 if B == 4 else 0.9, moll=200, side_eps=1e-2, device='cpu')
+        captured = {}
+        orig = _integ.solve_ivp
+
+        def spy(*a, _o=orig, **k):
+            sol = _o(*a, **k); captured['sol'] = sol; return sol
+        sampling.integrate.solve_ivp = spy
+        try:
+            x, nfe = fn(model, z=z, weight=0.5, class_labels=lab)
+        finally:
+            sampling.integrate.solve_ivp = orig
+        sol = captured['sol']
+        ks = sorted({0, 1, min(5, len(sol.t) - 2), (len(sol.t) - 1) // 2, len(sol.t) - 2})
+        out.update({f'{tag}.z': z.numpy(), f'{tag}.labels': lab.numpy(), f'{tag}.x': x.numpy(), f'{tag}.nfev': np.int64(nfe),
+                    f'{tag}.t': sol.t, f'{tag}.ks': np.array(ks)})
+        for k in ks:
+            out[f'{tag}.y{k}'] = sol.y[:, k].copy()
+            out[f'{tag}.y{k + 1}'] = sol.y[:, k + 1].copy()
+    save('ode_rk45.npz', **out)
+
+
 def gen_init():
     """Reference init under torch.manual_seed(0): lets the build's parameter shell prove it consumes the torch RNG
     identically (same construction order)."""
@@ -358,6 +394,9 @@ def gen_gto_dataset():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['ode']:
+        gen_ode()
+        sys.exit(0)
     if sys.argv[1:] == ['train_w0']:
         gen_train_w0()
         sys.exit(0)
@@ -372,4 +411,5 @@ if __name__ == '__main__':
     gen_sampler()
     gen_train()
     gen_train_w0()
+    gen_ode()
     gen_init()

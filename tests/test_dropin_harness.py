@@ -150,6 +150,47 @@ def _check_ode_sampler(ge, dev, params, B, span):
     assert callable(sampling.get_sampling_fn(cfg, sde, (B, 1, 9, 9), 1e-3, dev))
 
 
+def _check_ode_device_vs_reference(ge, dev, g, tag, ks, full):
+    """The on-device RK45 (rdmi_ode_sample) against the REFERENCE's recorded scipy run (fixture ode_rk45.npz, made by
+    oracle/gen_golden.py from RD/sampling.py:342-392 on an injected prior; rtol = atol = 1e-5 as the reference sets them).
+    One-step parity: restart from the recorded float64 state y_k at t_k with first_step = |t_k+1 - t_k| and max_steps = 1: the
+    controller must accept that very step (t reached == t_k+1) and land on y_k+1.  Tolerance 5e-6: the state moves by
+    h * 1/2 g^2 |score| <= 0.01 per step, of which the 2e-4 score tolerance is 2e-6; the start state is passed as fp32.
+    Full run (GPU): nfev within two step attempts of the reference's and the final sample within 2e-3 -- a free run, so NOT the
+    contract: per-step differences of ~1e-6 are amplified by the flow (Lipschitz constant 1/2 g^2 |ds/dx| integrated over t) and a
+    borderline accept/reject flips the step sequence; measured 7.9e-4 at the worst of 324 elements."""
+    from rdmi import sampling, sde_lib
+    model, cfg, _ = ge.make_model(dev)
+    sde = sde_lib.RVESDE(0.01, 0.5, N=1000)
+    lab = torch.from_numpy(g[f'{tag}.labels']).to(dev)
+    B = lab.shape[0]
+    ts = g[f'{tag}.t']
+    for k in ks:
+        yk = torch.from_numpy(g[f'{tag}.y{k}'].astype(np.float32)).reshape(B, 1, 9, 9).to(dev)
+        class _From(sde_lib.RVESDE):                           # integrate from t_k (the sampler starts at sde.T)
+            T = property(lambda self, _t=float(ts[k]): _t)
+        sub = _From(0.01, 0.5, N=1000)
+        fn = sampling.get_ode_sampler(sub, (B, 1, 9, 9), eps=float(ts[-1]), moll=200, side_eps=1e-2, device=dev,
+                                      first_step=abs(float(ts[k + 1] - ts[k])), max_steps=1)
+        x, nfev = fn(model, z=yk, weight=0.5, class_labels=lab)
+        assert nfev == 7                                      # f(t_k, y_k) + 6 stages, no rejected attempt
+        assert abs(fn.last['t'] - float(ts[k + 1])) < 1e-12, (k, fn.last, ts[k + 1])
+        np.testing.assert_allclose(x.cpu().numpy().reshape(-1), g[f'{tag}.y{k + 1}'], rtol=0, atol=5e-6, err_msg=f'step {k}')
+        if k + 2 < len(ts) - 1:       # the controller's proposal bounds the step the reference accepted next (equal unless the
+            #                           reference first tried it and rejected, or this step itself followed a rejection: factor <= 1)
+            assert abs(float(ts[k + 2] - ts[k + 1])) <= fn.last['h_next'] * (1 + 2e-2)
+    if full:
+        fn = sampling.get_ode_sampler(sde, (B, 1, 9, 9), eps=float(ts[-1]), moll=200, side_eps=1e-2, device=dev)
+        x, nfev = fn(model, z=torch.from_numpy(g[f'{tag}.z']).to(dev), weight=0.5, class_labels=lab)
+        assert abs(nfev - int(g[f'{tag}.nfev'])) <= 12, (nfev, int(g[f'{tag}.nfev']))
+        np.testing.assert_allclose(x.cpu().numpy(), g[f'{tag}.x'], rtol=0, atol=2e-3)
+        # the generic scipy route over the HIP score function (fused=False) is the same sampler
+        fn2 = sampling.get_ode_sampler(sde, (B, 1, 9, 9), eps=float(ts[-1]), moll=200, side_eps=1e-2, device=dev, fused=False)
+        x2, nfev2 = fn2(model, z=torch.from_numpy(g[f'{tag}.z']).to(dev), weight=0.5, class_labels=lab)
+        assert abs(nfev2 - nfev) <= 12
+        np.testing.assert_allclose(x2.cpu().numpy(), x.cpu().numpy(), rtol=0, atol=2e-3)
+
+
 def _check_sample_hk(dev):
     """cube.sample_hk (RD/cube.py:52-70) = reflect(x + sigma z): inside the cube, exact against reflect() of the same draw,
     and for a large sigma the reflected heat kernel is (nearly) uniform: mean 1/2, variance 1/12."""
@@ -175,11 +216,11 @@ def test_dropin_and_harness_emulator(emu):
     _check_dropin_and_harness(ge, 'cpu', B=1, N=2, corrector='none')
 
 
-def test_ode_rhs_emulator(emu, params0):
-    """Right-hand side of the probability-flow ODE through the emulated HIP score call (the integration itself is
-    exercised on the GPU and, for the host logic, by test_ode_sampler_host_logic below)."""
+def test_ode_device_rk45_one_step_emulator(emu, golden):
+    """One adaptive RK45 step of the on-device ODE sampler (7 right-hand sides at B=1, CFG) against the reference's recorded
+    scipy step; the full integration runs on the GPU (test_ode_device_rk45_gpu)."""
     import __graft_entry__ as ge
-    _check_ode_sampler(ge, 'cpu', params0, B=1, span=0.0)
+    _check_ode_device_vs_reference(ge, 'cpu', golden('ode_rk45.npz'), 'b1', [1], full=False)
 
 
 def test_sample_hk_emulator(emu):
@@ -234,6 +275,15 @@ def test_ode_sampler_gpu(params0):
     import __graft_entry__ as ge
     ge.build()
     _check_ode_sampler(ge, torch.device('cuda:0'), params0, B=4, span=0.2)
+
+
+@pytest.mark.gpu
+def test_ode_device_rk45_gpu(golden):
+    import __graft_entry__ as ge
+    ge.build()
+    g = golden('ode_rk45.npz')
+    _check_ode_device_vs_reference(ge, torch.device('cuda:0'), g, 'b4', [int(k) for k in g['b4.ks']], full=True)
+    _check_ode_device_vs_reference(ge, torch.device('cuda:0'), g, 'b1', [int(k) for k in g['b1.ks']], full=True)
 
 
 @pytest.mark.gpu
