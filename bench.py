@@ -230,6 +230,24 @@ def variants(ge, dev, args, labels):
                      'frac': (dom['flops'] / (dom['ms'] * 1e-3) / 1e12) / PEAK_FP32_MFMA_TFLOPS,
                      'whole_path_frac_of_fp32_peak': (B / dt) * 2 * (args.num_scales - 1) * (2 if corr == 'langevin' else 1) * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS}
         del model
+    # the reference's own operating point is B = 4096-8192 per GPU: from 512 model samples on, the
+    # low-resolution half of the U-Net runs for 2 / 4 samples per workgroup (csrc/rdmi.hip: build_fused_program)
+    for name, Bv, Nv in (('batch_1024', 1024, 1000), ('batch_4096', 4096, 251)):
+        model, cfg, _ = ge.make_model(dev, num_scales=Nv)
+        sde = sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=Nv)
+        lab = torch.rand(Bv, 1, generator=torch.Generator().manual_seed(3)).to(dev)
+        fn = sampling.get_sampling_fn(cfg, sde, (Bv, 1, 9, 9), 1e-5, dev)
+        warm = sampling.get_sampling_fn(cfg, sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=6), (Bv, 1, 9, 9), 1e-5, dev)
+        warm(model, weight=0.0, class_labels=lab)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        x, nfe = fn(model, weight=0.0, class_labels=lab)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
+        per_1000 = dt / (Nv - 1) * 999                          # a shorter schedule is scaled per update (every update costs the same)
+        out[name] = {'value': Bv / per_1000, 'unit': 'trajectories/s', 'batch': Bv, 'num_scales_run': Nv, 'ms_per_update': 1e3 * dt / (Nv - 1),
+                     'plan': model._ctx[(str(dev), 9, 9)].path_info(),
+                     'whole_path_frac_of_fp32_peak': (Bv / per_1000) * 2 * 999 * GFLOP_PER_FORWARD / 1e3 / PEAK_FP32_MFMA_TFLOPS}
+        del model
     out['train_b128'] = train_variant(ge, dev, 128)
     return out
 

@@ -151,6 +151,21 @@ struct rdmi_ctx {
     long long* d_stamps = nullptr;       // diagnostic (RDMI_STAMPS=1)
     std::vector<std::string> fdesc;      // one line per fused op
     size_t fused_lds = 0;
+    // (the fields above are the CONSTRUCTION state of one program; finished programs live here, one per samples-per-workgroup)
+    struct FusedProg {
+        int S = 1; bool ok = false; std::string why;
+        std::vector<FOp> fprog; std::vector<FPatch> fpatch; std::vector<short> ftabs; std::vector<std::string> fdesc;
+        FOp* d_fprog = nullptr; short* d_ftabs = nullptr; float* d_spill = nullptr; size_t spill_per_sample = 0;
+        UnetArgs fargs{}; size_t fused_lds = 0;
+    };
+    std::vector<FusedProg> progs;
+    int s_min_wg = 256;                            // a program with S samples per workgroup is used from batch s_min_wg * S (RDMI_S_MIN_WG: tests)
+    const FusedProg* pick(int NB) const {          // the program with the most samples per workgroup that still fills the chip
+        const FusedProg* best = nullptr;
+        for (auto& q : progs) if (q.ok && (q.S == 1 || NB >= s_min_wg * q.S) && (!best || q.S > best->S)) best = &q;
+        return best;
+    }
+    bool fused_ready() const { return !progs.empty() && progs[0].ok; }
     std::map<std::string, size_t> wmap;  // packed-weight arena offsets by parameter prefix
     bool packed_valid = false;
     bool debug_taps = false;
@@ -654,8 +669,15 @@ struct FusedBuilder {
     struct Blk { int off, size; };
     std::vector<Blk> freel;
     int arena_lo = 0, high_water = 0;
-    std::map<std::string, int> tabcache;       // geometry key -> offset (in shorts) into ftabs
-    struct LT { int off = -1, C = 0, H = 0, W = 0, rs = 0, bytes = 0; int rows() const { return H * W; } };
+    std::map<std::string, int> tabcache;       // geometry key -> encoded table reference (region << 24 | offset in shorts)
+    std::vector<short> tabs1;                  // region 1: tables of the multi-sample (low-resolution) section, resident in LDS only during it
+    int tab1_lds = 0;                          // LDS byte offset of region 1 (an arena block of the low-resolution section)
+    struct LT { int off = -1, C = 0, H = 0, W = 0, rs = 0, bytes = 0, ns = 1; int hw() const { return H * W; } int rows() const { return ns * H * W; } };
+    int S = 1;                      // samples per workgroup of the program being built
+    int cur_samp = 0;               // sample slot the emitted ops belong to; -1: ops cover all S samples (low-resolution section)
+    int multi_slot_off = -1;        // LDS offset of the per-(sample, group) partial-sum slots of multi-sample fused GroupNorms
+    int ns_now() const { return cur_samp < 0 ? S : 1; }
+    int shift_of(int hw) { int sh = 0; while ((1 << sh) < hw) ++sh; if (cur_samp < 0 && (1 << sh) != hw) fail_("multi-sample ops need a power-of-two pixel count"); return cur_samp < 0 ? sh : 0; }
     size_t spill_floats = 0;
     bool failed = false;
     std::string why;
@@ -705,7 +727,7 @@ struct FusedBuilder {
             else ++i;
     }
     LT talloc(int C, int H, int W) {
-        LT t; t.C = C; t.H = H; t.W = W; t.rs = C + 4; t.bytes = H * W * t.rs * 4; t.off = alloc_bytes(t.bytes);
+        LT t; t.C = C; t.H = H; t.W = W; t.ns = ns_now(); t.rs = C + 4; t.bytes = t.ns * H * W * t.rs * 4; t.off = alloc_bytes(t.bytes);
         return t;
     }
     void tfree(LT& t) { if (t.off >= 0) free_bytes(t.off, t.bytes); t.off = -1; }
@@ -714,25 +736,29 @@ struct FusedBuilder {
     int add_table(const std::string& key, const std::vector<short>& v) {
         auto it = tabcache.find(key);
         if (it != tabcache.end()) return it->second;
-        while (c->ftabs.size() % 2) c->ftabs.push_back(-1);
-        const int off = (int)c->ftabs.size();
-        c->ftabs.insert(c->ftabs.end(), v.begin(), v.end());
+        const int region = (S > 1 && cur_samp < 0) ? 1 : 0;
+        std::vector<short>& tb = region ? tabs1 : c->ftabs;
+        while (tb.size() % 2) tb.push_back(-1);
+        const int off = (int)tb.size() | (region << 24);
+        tb.insert(tb.end(), v.begin(), v.end());
         tabcache[key] = off;
         return off;
     }
     // tap table of a conv reading tensor (Hs x Ws) seen as a virtual (Hv x Wv) grid (nearest), output (Ho x Wo)
     int tap_table(int Hs, int Ws, int Hv, int Wv, int Ho, int Wo, int stride, int pad_lo, int tap) {
         char key[128];
-        snprintf(key, sizeof key, "tap:%d,%d,%d,%d,%d,%d,%d,%d,%d", Hs, Ws, Hv, Wv, Ho, Wo, stride, pad_lo, tap);
-        const int Mpad = pad16(Ho * Wo);
+        const int ns = ns_now();                       // multi-sample: block-diagonal (row s*HWo + p reads source row s*HWs + ...)
+        snprintf(key, sizeof key, "tap:%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", Hs, Ws, Hv, Wv, Ho, Wo, stride, pad_lo, tap, ns);
+        const int Mpad = pad16(ns * Ho * Wo);
         std::vector<short> v((size_t)Mpad, (short)-1);
-        for (int m = 0; m < Ho * Wo; ++m) {
-            const int oy = m / Wo, ox = m % Wo;
+        for (int m = 0; m < ns * Ho * Wo; ++m) {
+            const int sm = m / (Ho * Wo), pm = m % (Ho * Wo);
+            const int oy = pm / Wo, ox = pm % Wo;
             const int iy = oy * stride + tap / 3 - pad_lo, ix = ox * stride + tap % 3 - pad_lo;
             if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) continue;
             const int sy = std::min((int)std::floor(iy * ((float)Hs / Hv)), Hs - 1);
             const int sx = std::min((int)std::floor(ix * ((float)Ws / Wv)), Ws - 1);
-            v[(size_t)m] = (short)(sy * Ws + sx);
+            v[(size_t)m] = (short)(sm * Hs * Ws + sy * Ws + sx);
         }
         return add_table(key, v);
     }
@@ -760,7 +786,7 @@ struct FusedBuilder {
     FOp blank(int kind) {
         FOp o;
         std::memset(&o, 0, sizeof o);
-        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1; o.gn_off = -1;
+        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1; o.gn_off = -1; o.samp = cur_samp;
         return o;
     }
     int emit(const FOp& o) { c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
@@ -771,34 +797,46 @@ struct FusedBuilder {
     void gather_x(const LT& dst) {               // network input -> LDS [HW][16+4]
         FOp o = blank(FOP_GATHER);
         o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
-        o.CA = c->arch.channels; o.CB = 0; o.a_off = -2; o.a_hw = dst.rows();
+        o.CA = c->arch.channels; o.CB = 0; o.a_off = -2; o.a_hw = dst.hw(); o.hw_shift = shift_of(dst.hw());
         emit(o);
+    }
+    // dst = a tensor parked in this workgroup's spill slot `spill` ([n][hw][C]); single- or multi-sample by the current mode
+    void gather_g(const LT& dst, size_t spill) {
+        FOp o = blank(FOP_GATHER);
+        o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
+        o.CA = dst.C; o.CB = 0; o.a_off = -1; o.a_hw = dst.hw(); o.a_mod = 0; o.hw_shift = shift_of(dst.hw());
+        const int idx = emit(o);
+        spill_fix.push_back({idx, spill, 2});
     }
     // dst = concat(A (LDS tensor, nearest-mapped onto dst's grid), B (global spill slot))
     void gather_cat(const LT& dst, const LT& A, size_t spillB, int CB) {
         FOp o = blank(FOP_GATHER);
         o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
-        o.CA = A.C; o.CB = CB; o.a_off = A.off; o.a_rs = A.rs;
+        o.CA = A.C; o.CB = CB; o.a_off = A.off; o.a_rs = A.rs; o.a_hw = A.hw(); o.hw_shift = shift_of(dst.hw());
         if (A.H != dst.H || A.W != dst.W) o.a_map_off = map_table(A.H, A.W, dst.H, dst.W);
-        o.b_off = -1; o.b_g = c->d_spill ? nullptr : nullptr;
+        o.b_off = -1;
         const int idx = emit(o);
-        spill_fix.push_back({idx, spillB, true});
+        spill_fix.push_back({idx, spillB, 1});
     }
     void copy_t(const LT& dst, const LT& src) {
         FOp o = blank(FOP_GATHER);
         o.dst_off = dst.off; o.dst_rs = dst.rs; o.rows = dst.rows(); o.C = dst.C;
-        o.CA = src.C; o.CB = 0; o.a_off = src.off; o.a_rs = src.rs;
+        o.CA = src.C; o.CB = 0; o.a_off = src.off; o.a_rs = src.rs; o.a_hw = src.hw(); o.hw_shift = shift_of(dst.hw());
         emit(o);
     }
-    struct SpillFix { int op; size_t off; bool is_b; };
+    struct SpillFix { int op; size_t off; int which; };      // which: 0 STORE destination, 1 GATHER source B, 2 GATHER source A
+    // Per-sample sections of a multi-sample program are emitted once per sample slot: the spill slots they use must be the
+    // SAME for every slot (the buffer is [slot][n][rows][C]); the first emission records them, the others replay them.
+    std::vector<size_t> slot_log; size_t slot_pos = 0; bool slot_replay = false;
     std::vector<SpillFix> spill_fix;
     size_t spill_store(const LT& t) {            // LDS tensor -> this workgroup's slot of the spill buffer
         FOp o = blank(FOP_STORE);
-        o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
+        o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C; o.hw_shift = shift_of(t.hw());
         const int idx = emit(o);
-        const size_t off = spill_floats;
-        spill_floats += (size_t)t.rows() * t.C;
-        spill_fix.push_back({idx, off, false});
+        size_t off;
+        if (slot_replay) { if (slot_pos >= slot_log.size()) { fail_("spill replay out of slots"); return 0; } off = slot_log[slot_pos++]; }
+        else { off = spill_floats; spill_floats += (size_t)t.hw() * t.C; slot_log.push_back(off); }
+        spill_fix.push_back({idx, off, 0});
         return off;
     }
     // GroupNorm (+SiLU) of tensor t (in place), or of `src` into t (copy form).  When the tensor being normalised is the
@@ -817,11 +855,12 @@ struct FusedBuilder {
         const int lWN = (ntiles >= 8 && (ntiles & 7) == 0) ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // as fop_conv
         const int WN = 1 << lWN, WM = UW_WAVES >> lWN;
         if (ntiles > WN || p.mtiles > 4 * WM) return false;                    // a wave would make several passes
-        const int nslots = WM * 4;
-        if ((t.C / 4) * nslots * 8 > 1024) return false;
+        const int nslots = p.samp >= 0 ? WM * 4 : 4;
+        if (p.samp >= 0) { if ((t.C / 4) * nslots * 8 > 1024) return false; }
+        else if (multi_slot_off < 0 || t.ns * (t.C / 4) * 32 > 4096 || (t.hw() != 16 && t.hw() != 4)) return false;
         p.gn_off = t.off; p.gn_rs = t.rs; p.gn_act = act ? 1 : 0; p.gn_raw = src ? 1 : 0;
-        p.gn_slot_off = gn_slot_off; p.gn_nslots = nslots;
-        p.eps = 1e-6f; p.inv_cnt = 1.0f / (float)(4 * t.rows());
+        p.gn_slot_off = p.samp >= 0 ? gn_slot_off : multi_slot_off; p.gn_nslots = nslots;
+        p.eps = 1e-6f; p.inv_cnt = 1.0f / (float)(4 * t.hw());
         patch_param(j, F_GAMMA, pre + ".weight"); patch_param(j, F_BETA, pre + ".bias");
         ++n_gn_fused;
         return true;
@@ -832,15 +871,16 @@ struct FusedBuilder {
         FOp o = blank(FOP_GN);
         if (src) { o.src_off = src->off; o.src_rs = src->rs; }
         o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
-        o.G = std::min(t.C / 4, 32); o.act = act ? 1 : 0; o.eps = 1e-6f;
+        o.G = std::min(t.C / 4, 32); o.act = act ? 1 : 0; o.eps = 1e-6f; o.hw_shift = shift_of(t.hw());
         {
             const int T = UW_THREADS / o.G, c4n = t.C / 4;
             o.logT = T == 32 ? 5 : (T == 16 ? 4 : (T == 64 ? 6 : 3));
             o.Cg = t.C / o.G;
             o.magic_c4n = (65536 + c4n - 1) / c4n; o.magic_Cg = (65536 + o.Cg - 1) / o.Cg;
-            o.inv_cnt = 1.0f / (float)(o.Cg * t.rows());
+            o.inv_cnt = 1.0f / (float)(o.Cg * t.hw());
             if ((1 << o.logT) != T) fail_("GroupNorm lanes-per-group not a power of two");
-            if (ceil_div(t.rows(), T) > 6 || o.Cg > 8) fail_("GroupNorm group too large for the register-resident statistics");
+            if (t.ns * o.G * 8 > 1024) fail_("GroupNorm statistics of all samples exceed the scratch region");
+            if (ceil_div(t.hw(), T) > 6 || o.Cg > 8) fail_("GroupNorm group too large for the register-resident statistics");
         }
         if (t.C % o.G != 0 || UW_THREADS % o.G != 0 || UW_THREADS / o.G > 64) fail_("GroupNorm shape C=" + std::to_string(t.C));
         const int idx = emit(o);
@@ -853,20 +893,22 @@ struct FusedBuilder {
              float scale, int dense_off, const LT* resid, const LT* sc_src, const std::string& sc_key,
              const std::string& bias2_param) {
         FOp o = blank(FOP_CONV);
-        o.rows = Ho * Wo; o.mtiles = pad16(Ho * Wo) / 16; o.Cout = Cout; o.Cout_pad = pad16(Cout);
-        o.ntap = ntap;
+        const int ns = ns_now();
+        o.rows = ns * Ho * Wo; o.mtiles = pad16(o.rows) / 16; o.Cout = Cout; o.Cout_pad = pad16(Cout);
+        o.ntap = ntap; o.hw_shift = shift_of(Ho * Wo);
+        if (ns > 1 && dst_kind != 0) fail_("multi-sample convs write LDS tensors only");
         o.main_ph.lds_off = in.off; o.main_ph.rs = in.rs; o.main_ph.nch = pad16(in.C) / 16;
         if (in.C % 16 != 0) fail_("conv input channels not padded");
         for (int t = 0; t < ntap; ++t)
-            o.tab_off[t] = ntap == 1 ? ident_table(Ho * Wo) : tap_table(in.H, in.W, Hv, Wv, Ho, Wo, stride, pad_lo, t);
+            o.tab_off[t] = ntap == 1 ? ident_table(ns * Ho * Wo) : tap_table(in.H, in.W, Hv, Wv, Ho, Wo, stride, pad_lo, t);
         o.dense_off = dense_off; o.scale = scale; o.dst_kind = dst_kind;
         if (dst) { o.dst_off = dst->off; o.dst_rs = dst->rs; }
         if (resid) { o.resid_off = resid->off; o.resid_rs = resid->rs; }
-        if (o.mtiles > 6) fail_("conv with more than 96 output pixels per sample");
+        if (o.mtiles > 6) fail_("conv with more than 96 output rows per workgroup");
         if (sc_src) fail_("fused CONV ops carry no shortcut phases (the NIN shortcut is its own 1x1 op)");
         if (sc_src) {
             o.nsc = 1;
-            o.sc[0].lds_off = sc_src->off; o.sc[0].rs = sc_src->rs; o.sc[0].nch = sc_src->C / 16; o.sc[0].tab_off = ident_table(Ho * Wo);
+            o.sc[0].lds_off = sc_src->off; o.sc[0].rs = sc_src->rs; o.sc[0].nch = sc_src->C / 16; o.sc[0].tab_off = ident_table(ns * Ho * Wo);
         }
         const int idx = emit(o);
         patch_arena(idx, F_W, c->wmap.at(wkey) + w_extra_off);
@@ -915,6 +957,7 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
     rdmi_ctx* c = b.c;
     const int C = x.C, H = x.H, W = x.W, L = H * W, Lpad = pad16(L);
     if (C != 64 || Lpad > 96) { b.fail_("attention: only C=64, H*W<=96 is built"); return x; }
+    if (b.cur_samp < 0) { b.fail_("attention inside the multi-sample (low-resolution) section is not built"); return x; }
     LT xn = b.talloc(C, H, W);
     b.gn(xn, name + ".GroupNorm_0", false, &x);
     LT q = b.talloc(C, H, W), k = b.talloc(C, H, W);
@@ -947,23 +990,50 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
     return out;
 }
 
-int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used);
+int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used);
 
-int build_fused_program(rdmi_ctx* c) {
-    int used = 0;
-    if (int e = build_fused_program_pass(c, 8 * 1024, &used)) return e;
+// A built program is moved out of the context's construction fields into one of these (one per samples-per-workgroup value).
+void stash_program(rdmi_ctx* c, int S) {
+    rdmi_ctx::FusedProg q;
+    q.S = S; q.ok = c->fused_ok; q.why = c->fused_why;
+    q.fprog.swap(c->fprog); q.fpatch.swap(c->fpatch); q.ftabs.swap(c->ftabs); q.fdesc.swap(c->fdesc);
+    q.d_fprog = c->d_fprog; q.d_ftabs = c->d_ftabs; q.d_spill = c->d_spill; q.spill_per_sample = c->spill_per_sample;
+    q.fargs = c->fargs; q.fused_lds = c->fused_lds;
+    c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr; c->spill_per_sample = 0; c->fused_ok = false; c->fused_why.clear();
+    c->progs.push_back(std::move(q));
+}
+
+int build_one_program(rdmi_ctx* c, int S) {
+    int used = 0, used1 = 0;
+    if (int e = build_fused_program_pass(c, S, 8 * 1024, 24 * 1024, &used, &used1)) return e;
     if (c->fused_ok) {   // second pass with the table region sized exactly
         for (void* p : {(void*)c->d_fprog, (void*)c->d_ftabs, (void*)c->d_spill}) if (p) (void)hipFree(p);
         c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr;
     }
     c->fused_ok = false; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); c->fused_why.clear();
-    return build_fused_program_pass(c, (used + 63) & ~63, &used);
+    if (int e = build_fused_program_pass(c, S, (used + 63) & ~63, (used1 + 63) & ~63, &used, &used1)) return e;
+    stash_program(c, S);
+    return 0;
 }
 
-int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
+int build_fused_program(rdmi_ctx* c) {
+    // S = 1: one sample per workgroup (B <= 128 with guidance fills the 256 CUs exactly).  Larger batches run the
+    // low-resolution half of the network for S = 2 / 4 samples at once per workgroup: every streamed weight fragment then
+    // feeds S samples (that half is weight-stream bound at S = 1) and its per-op fixed cost is shared.
+    if (int e = build_one_program(c, 1)) return e;
+    const char* only = std::getenv("RDMI_S");           // RDMI_S=1 keeps the single-sample program only (A/B)
+    if (const char* e = std::getenv("RDMI_S_MIN_WG")) c->s_min_wg = std::max(1, atoi(e));
+    for (int S : {2, 4})
+        if (c->progs[0].ok && c->arch.n_levels >= 2 && c->max_batch >= c->s_min_wg * S && (!only || atoi(only) >= S))
+            if (int e = build_one_program(c, S)) return e;
+    return 0;
+}
+
+int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used) {
     using LT = FusedBuilder::LT;
     const rdmi_arch& a = c->arch;
     FusedBuilder b{c};
+    b.S = S;
     Layout L = build_layout(c);
     std::map<std::string, int> dense_off;
     {
@@ -975,45 +1045,133 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     }
     // LDS: [row tables] [zero row] [GN stats] [tensor arena]
     const int zero_bytes = 1280;                     // >= (Cmax/16)*64 + 64 for Cmax = 256... host-checked below
-    const int stat_bytes = 1024 + 64;                         // GN op scratch [2 x 32] overlaid with the fused-GroupNorm partial-sum slots (never live together)
+    const int stat_bytes = 1024 + 64;                         // GN op scratch [S][2 x 32] overlaid with the fused-GroupNorm partial-sum slots (never live together)
     b.arena_init(TAB_RESERVE + zero_bytes + stat_bytes);
     b.gn_slot_off = TAB_RESERVE + zero_bytes;
     b.gn_fuse = std::getenv("RDMI_NO_GNFUSE") == nullptr;
-    int H = c->H, W = c->W;
-    if (H * W > 96) { c->fused_why = "more than 96 pixels per sample"; return 0; }
+    const int H0 = c->H, W0 = c->W;
+    if (H0 * W0 > 96) { c->fused_why = "more than 96 pixels per sample"; return 0; }
+    const int nlev = a.n_levels;
+    const bool multi = S > 1;
 
-    LT xin = b.talloc(16, H, W);
-    b.gather_x(xin);
-    LT h = b.talloc(a.nf, H, W);
-    b.conv(xin, H, W, H, W, 1, 1, 9, "input_conv", 0, a.nf, "input_conv.bias", 0, 0, &h, 1.f, -1, nullptr, nullptr, "", "");
-    b.tfree(xin);
     struct HS { size_t spill; int C, H, W; };
-    std::vector<HS> hs;
-    hs.push_back({(size_t)-1, a.nf, H, W});          // hs[0] (input_conv output) is never popped (RD/models/ncsnpp.py:268,315)
-    int ch = a.nf, d = 0;
-    for (int i = 0; i < a.n_levels; ++i) {
-        for (int j = 0; j < a.num_res_blocks; ++j, ++d) {
-            const BlockSpec& bs = L.down[(size_t)d];
+    std::vector<HS> hs;                               // the skip stack (RD/models/ncsnpp.py:268-292, 311-338)
+    int ch = a.nf, H = H0, W = W0;
+    size_t hand_down = 0, hand_up = 0;                // multi-sample: level-0 <-> low-resolution hand-off slots
+    LT h;
+    // ---- level 0, down path: once per sample slot (same LDS, same spill slots)
+    const int nrb = a.num_res_blocks;
+    for (int sl = 0; sl < S; ++sl) {
+        b.cur_samp = sl;
+        b.slot_replay = sl > 0; b.slot_pos = 0;
+        H = H0; W = W0; ch = a.nf;
+        LT xin = b.talloc(16, H, W);
+        b.gather_x(xin);
+        h = b.talloc(a.nf, H, W);
+        b.conv(xin, H, W, H, W, 1, 1, 9, "input_conv", 0, a.nf, "input_conv.bias", 0, 0, &h, 1.f, -1, nullptr, nullptr, "", "");
+        b.tfree(xin);
+        if (sl == 0) hs.push_back({(size_t)-1, a.nf, H, W});          // hs[0] (input_conv output) is never popped (RD/models/ncsnpp.py:268,315)
+        for (int j = 0; j < nrb; ++j) {
+            const BlockSpec& bs = L.down[(size_t)j];
             h = fused_resblock(b, bs.name, h, bs.cout, dense_off[bs.name]);
             ch = bs.cout;
-            if (bs.attn) h = fused_attn(b, "down_attn." + std::to_string(d), h);
-            hs.push_back({b.spill_store(h), ch, H, W});
+            if (bs.attn) h = fused_attn(b, "down_attn." + std::to_string(j), h);
+            const size_t sp = b.spill_store(h);
+            if (sl == 0) hs.push_back({sp, ch, H, W});
         }
-        hs.push_back(hs.back());
-        if (i != a.n_levels - 1) {
+        if (sl == 0) hs.push_back(hs.back());
+        if (nlev > 1) {
             const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
             LT o = b.talloc(ch, Ho, Wo);
-            const std::string nm = "downsample." + std::to_string(i) + ".Conv_0";
+            const std::string nm = "downsample.0.Conv_0";
             b.conv(h, H, W, Ho, Wo, 2, 0, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
             b.tfree(h);
             h = o; H = Ho; W = Wo;
+            if (multi) { hand_down = b.spill_store(h); b.tfree(h); }
         }
     }
-    h = fused_resblock(b, "mid_block1", h, ch, dense_off["mid_block1"]);
-    h = fused_resblock(b, "mid_block2", h, ch, dense_off["mid_block2"]);
-    int u = 0;
-    for (int k = 0; k < a.n_levels; ++k) {
-        for (int j = 0; j < a.num_res_blocks + 1; ++j, ++u) {
+    b.slot_replay = false;
+    // ---- levels >= 1 (down), bottleneck, levels >= 1 (up): all S samples at once when S > 1
+    int d = nrb, u = 0, loadtab_idx = -1;
+    {
+        b.cur_samp = multi ? -1 : 0;
+        int loadtab_op = -1;
+        if (multi) {
+            b.multi_slot_off = b.alloc_top(4096);
+            b.tab1_lds = b.alloc_top(TAB1_RESERVE);
+            FOp lt = b.blank(FOP_LOADTAB);            // the section's row tables: global -> LDS (source / size patched below)
+            lt.dst_off = b.tab1_lds;
+            loadtab_op = b.emit(lt);
+            h = b.talloc(ch, H, W);
+            b.gather_g(h, hand_down);
+        }
+        for (int i = 1; i < nlev; ++i) {
+            for (int j = 0; j < nrb; ++j, ++d) {
+                const BlockSpec& bs = L.down[(size_t)d];
+                h = fused_resblock(b, bs.name, h, bs.cout, dense_off[bs.name]);
+                ch = bs.cout;
+                if (bs.attn) h = fused_attn(b, "down_attn." + std::to_string(d), h);
+                hs.push_back({b.spill_store(h), ch, H, W});
+            }
+            hs.push_back(hs.back());
+            if (i != nlev - 1) {
+                const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+                LT o = b.talloc(ch, Ho, Wo);
+                const std::string nm = "downsample." + std::to_string(i) + ".Conv_0";
+                b.conv(h, H, W, Ho, Wo, 2, 0, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
+                b.tfree(h);
+                h = o; H = Ho; W = Wo;
+            }
+        }
+        h = fused_resblock(b, "mid_block1", h, ch, dense_off["mid_block1"]);
+        h = fused_resblock(b, "mid_block2", h, ch, dense_off["mid_block2"]);
+        for (int k = 0; k < nlev - 1; ++k) {          // up levels nlev-1 .. 1
+            for (int j = 0; j < nrb + 1; ++j, ++u) {
+                const BlockSpec& bs = L.up[(size_t)u];
+                HS sk = hs.back();
+                hs.pop_back();
+                LT cat = b.talloc(ch + sk.C, sk.H, sk.W);
+                b.gather_cat(cat, h, sk.spill, sk.C);
+                b.tfree(h);
+                H = sk.H; W = sk.W;
+                h = fused_resblock(b, bs.name, cat, bs.cout, dense_off[bs.name]);
+                ch = bs.cout;
+                if (bs.attn) h = fused_attn(b, "up_attn." + std::to_string(u), h);
+            }
+            if (k != nlev - 2) {                       // upsample between two low levels stays in this section
+                LT o = b.talloc(ch, 2 * H, 2 * W);
+                const std::string nm = "upsample." + std::to_string(k) + ".Conv_0";
+                b.conv(h, 2 * H, 2 * W, 2 * H, 2 * W, 1, 1, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
+                b.tfree(h);
+                h = o; H *= 2; W *= 2;
+            }
+        }
+        if (multi) {
+            hand_up = b.spill_store(h);
+            b.tfree(h);
+            b.free_bytes(b.multi_slot_off, 4096);
+            b.multi_slot_off = -1;
+            b.free_bytes(b.tab1_lds, TAB1_RESERVE);
+            while (b.tabs1.size() % 8) b.tabs1.push_back(-1);
+            c->fprog[(size_t)loadtab_op].rows = (int)b.tabs1.size() * 2;      // bytes
+        }
+        loadtab_idx = loadtab_op;
+    }
+    // ---- level 0, up path: once per sample slot
+    const int u0 = u, ch_low = ch, H_low = H, W_low = W;
+    const std::vector<HS> hs0 = hs;
+    for (int sl = 0; sl < S; ++sl) {
+        b.cur_samp = sl;
+        u = u0; ch = ch_low; H = H_low; W = W_low; hs = hs0;
+        if (multi) { h = b.talloc(ch, H, W); b.gather_g(h, hand_up); }
+        if (nlev > 1) {                                // the upsample conv onto level 0's (even) grid
+            LT o = b.talloc(ch, 2 * H, 2 * W);
+            const std::string nm = "upsample." + std::to_string(nlev - 2) + ".Conv_0";
+            b.conv(h, 2 * H, 2 * W, 2 * H, 2 * W, 1, 1, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
+            b.tfree(h);
+            h = o; H *= 2; W *= 2;
+        }
+        for (int j = 0; j < nrb + 1; ++j, ++u) {
             const BlockSpec& bs = L.up[(size_t)u];
             HS sk = hs.back();
             hs.pop_back();
@@ -1025,20 +1183,16 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
             ch = bs.cout;
             if (bs.attn) h = fused_attn(b, "up_attn." + std::to_string(u), h);
         }
-        if (k != a.n_levels - 1) {
-            LT o = b.talloc(ch, 2 * H, 2 * W);
-            const std::string nm = "upsample." + std::to_string(k) + ".Conv_0";
-            b.conv(h, 2 * H, 2 * W, 2 * H, 2 * W, 1, 1, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
-            b.tfree(h);
-            h = o; H *= 2; W *= 2;
-        }
+        b.gn(h, "out_norm", true);
+        b.conv(h, H, W, H, W, 1, 1, 9, "out_conv", 0, a.channels, "out_conv.bias", 0, 2, nullptr, 1.f, -1, nullptr, nullptr, "", "");
+        b.tfree(h);
     }
-    b.gn(h, "out_norm", true);
-    b.conv(h, H, W, H, W, 1, 1, 9, "out_conv", 0, a.channels, "out_conv.bias", 0, 2, nullptr, 1.f, -1, nullptr, nullptr, "", "");
-    b.tfree(h);
+    if (H != c->H || W != c->W) b.fail_("network output grid differs from the input grid");
 
     *tab_used = (int)c->ftabs.size() * 2 + 16;
+    *tab1_used = (int)b.tabs1.size() * 2 + 16;
     if (*tab_used > TAB_RESERVE && TAB_RESERVE != 8 * 1024) b.fail_("row tables exceed the reserved LDS region");
+    if (*tab1_used > TAB1_RESERVE && multi) b.fail_("low-resolution row tables exceed their LDS block");
     int cmax = 16;
     for (auto& o : c->fprog) if (o.kind == FOP_CONV) { cmax = std::max(cmax, o.main_ph.nch * 16); for (int s2 = 0; s2 < o.nsc; ++s2) cmax = std::max(cmax, o.sc[s2].nch * 16); }
     if (cmax * 4 + 64 > zero_bytes) b.fail_("zero row too small");
@@ -1046,15 +1200,18 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     if (b.failed) { c->fused_why = b.why; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); return 0; }
 
     // table offsets (shorts, relative) -> LDS byte offsets
+    auto tab_lds = [&](int ref) { return (ref >> 24) ? b.tab1_lds + (ref & 0xffffff) * 2 : (ref & 0xffffff) * 2; };
     for (auto& o : c->fprog) {
         if (o.kind == FOP_CONV) {
-            for (int t = 0; t < o.ntap; ++t) o.tab_off[t] = o.tab_off[t] * 2;
-            for (int s2 = 0; s2 < o.nsc; ++s2) o.sc[s2].tab_off = o.sc[s2].tab_off * 2;
+            for (int t = 0; t < o.ntap; ++t) o.tab_off[t] = tab_lds(o.tab_off[t]);
+            for (int s2 = 0; s2 < o.nsc; ++s2) o.sc[s2].tab_off = tab_lds(o.sc[s2].tab_off);
         } else if (o.kind == FOP_GATHER && o.a_map_off >= 0) {
-            o.a_map_off = o.a_map_off * 2;
+            o.a_map_off = tab_lds(o.a_map_off);
         }
     }
     while (c->ftabs.size() % 8) c->ftabs.push_back(-1);
+    const size_t tab0_shorts = c->ftabs.size();                  // region 0 is what the kernel copies at start; region 1 follows it in the buffer
+    c->ftabs.insert(c->ftabs.end(), b.tabs1.begin(), b.tabs1.end());
     c->spill_per_sample = b.spill_floats;
     HIP_OK(hipMalloc((void**)&c->d_spill, std::max<size_t>(c->spill_per_sample, 1) * (size_t)c->max_batch * sizeof(float)));
     HIP_OK(hipMalloc((void**)&c->d_fprog, c->fprog.size() * sizeof(FOp)));
@@ -1064,20 +1221,21 @@ int build_fused_program_pass(rdmi_ctx* c, int TAB_RESERVE, int* tab_used) {
     for (auto& f : b.spill_fix) {
         FOp& o = c->fprog[(size_t)f.op];
         float* p = c->d_spill + f.off * (size_t)c->max_batch;
-        if (f.is_b) o.b_g = p; else o.g_out = p;
+        if (f.which == 1) o.b_g = p; else if (f.which == 2) o.a_g = p; else o.g_out = p;
     }
     c->fargs = UnetArgs{};
     c->fargs.prog = c->d_fprog; c->fargs.nops = (int)c->fprog.size();
-    c->fargs.tabs = c->d_ftabs; c->fargs.tab_bytes = (int)(c->ftabs.size() * sizeof(short)); c->fargs.tab_base = 0;
+    c->fargs.tabs = c->d_ftabs; c->fargs.tab_bytes = (int)(tab0_shorts * sizeof(short)); c->fargs.tab_base = 0;
+    if (loadtab_idx >= 0) c->fprog[(size_t)loadtab_idx].a_g = reinterpret_cast<const float*>(c->d_ftabs + tab0_shorts);
     c->fargs.zero_off = TAB_RESERVE; c->fargs.zero_bytes = zero_bytes;
-    c->fargs.dense = c->d_dense; c->fargs.dense_stride = c->dense_total;
+    c->fargs.dense = c->d_dense; c->fargs.dense_stride = c->dense_total; c->fargs.S = S;
     c->fused_lds = (size_t)b.high_water;
     if (const char* e = std::getenv("RDMI_UDBG")) c->fargs.dbg = atoi(e);
-    if (std::getenv("RDMI_STAMPS")) { HIP_OK(hipMalloc((void**)&c->d_stamps, (1024 + c->fprog.size() * 8 + 8) * sizeof(long long))); c->fargs.stamps = c->d_stamps; }
+    if (std::getenv("RDMI_STAMPS") && S == 1 && !c->d_stamps) { HIP_OK(hipMalloc((void**)&c->d_stamps, (1024 + c->fprog.size() * 8 + 8) * sizeof(long long))); c->fargs.stamps = c->d_stamps; }
     c->fdesc.clear();
     for (auto& o : c->fprog) {
         char buf[160];
-        const char* kn[] = {"GATHER", "STORE", "GN", "CONV", "ATTN"};
+        const char* kn[] = {"GATHER", "STORE", "GN", "CONV", "ATTN", "LOADTAB"};
         if (o.kind == FOP_CONV) snprintf(buf, sizeof buf, "CONV rows=%d mtiles=%d K=%dx%d(+%d) Cout=%d dst=%d%s", o.rows, o.mtiles, o.ntap, o.main_ph.nch * 16, o.nsc ? o.sc[0].nch * 16 : 0, o.Cout, o.dst_kind, o.gn_off >= 0 ? (o.gn_raw ? " +GN(copy)" : " +GN") : "");
         else snprintf(buf, sizeof buf, "%s rows=%d C=%d", kn[o.kind], o.rows, o.C);
         c->fdesc.push_back(buf);
@@ -1183,9 +1341,10 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
             op.attn.gamma = P(c, op.p_gamma); op.attn.beta = P(c, op.p_beta); op.attn.b3 = P(c, op.p_b3);
         }
     }
-    if (c->fused_ok) {
-        for (auto& f : c->fpatch) {
-            FOp& o = c->fprog[(size_t)f.op];
+    for (auto& q : c->progs) {
+        if (!q.ok) continue;
+        for (auto& f : q.fpatch) {
+            FOp& o = q.fprog[(size_t)f.op];
             const float* p = f.param.empty() ? c->d_w + f.arena_off : P(c, f.param);
             switch (f.field) {
                 case FusedBuilder::F_GAMMA: o.gamma = p; break;
@@ -1197,9 +1356,9 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
                 case FusedBuilder::F_SC1W: o.sc[1].w = p; break;
             }
         }
-        HIP_OK(hipMemcpyAsync(c->d_fprog, c->fprog.data(), c->fprog.size() * sizeof(FOp), hipMemcpyHostToDevice, s));
-        HIP_OK(hipStreamSynchronize(s));
+        HIP_OK(hipMemcpyAsync(q.d_fprog, q.fprog.data(), q.fprog.size() * sizeof(FOp), hipMemcpyHostToDevice, s));
     }
+    if (c->fused_ready()) HIP_OK(hipStreamSynchronize(s));
     c->packed_valid = true;
     return 0;
 }
@@ -1257,21 +1416,25 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     }
     HIP_OK(hipGetLastError());
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
-    if (c->fused_ok && c->use_fused && !c->debug_taps) {
+    const rdmi_ctx::FusedProg* fq = (c->use_fused && !c->debug_taps) ? c->pick(f.NB) : nullptr;
+    if (fq) {
         static bool attr_set = false;
         if (!attr_set) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        UnetArgs ua = c->fargs;
+        UnetArgs ua = fq->fargs;
         ua.x_in = f.x; ua.x_mod = f.x_mod; ua.out = f.out; ua.NB = f.NB;
+        const unsigned nwg = (unsigned)ceil_div(f.NB, fq->S);
         if (f.dense_rows) ua.dense = f.dense_rows;
         double fl = 0;
         for (auto& op : c->ops) fl += op.flops_per_sample;
         ProfScope ps(c, s, "unet_wg_kernel", fl * f.NB);
-        if (ua.stamps || ua.dbg) hipLaunchKernelGGL(unet_wg_kernel<true>, dim3((unsigned)f.NB), dim3(UW_THREADS), c->fused_lds, s, ua);   // diagnostic build
-        else hipLaunchKernelGGL(unet_wg_kernel<false>, dim3((unsigned)f.NB), dim3(UW_THREADS), c->fused_lds, s, ua);
+        if ((ua.stamps || ua.dbg) && fq->S == 1) hipLaunchKernelGGL(unet_wg_kernel<true>, dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);   // diagnostic build
+        else if (fq->S > 1) hipLaunchKernelGGL((unet_wg_kernel<false, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
+        else hipLaunchKernelGGL(unet_wg_kernel<false>, dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
         HIP_OK(hipGetLastError());
         return 0;
     }
@@ -1306,8 +1469,9 @@ extern "C" {
 
 const char* rdmi_last_error(void) { return g_err.c_str(); }
 int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** desc, int desc_cap) {
-    if (!c || !c->d_stamps) return 0;
-    const int n = (int)c->fprog.size();
+    if (!c || !c->d_stamps || !c->fused_ready()) return 0;
+    const rdmi_ctx::FusedProg& q0 = c->progs[0];
+    const int n = (int)q0.fprog.size();
     std::vector<long long> st((size_t)n + 1);
     if (n > 1000) return 0;
     if (hipMemcpy(st.data(), c->d_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
@@ -1319,15 +1483,21 @@ int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** des
             for (int i = 0; i < n && 256 + i * 6 + 5 < cap; ++i)
                 for (int k = 0; k < 6; ++k) host[256 + i * 6 + k] = fs[(size_t)i * 8 + k] - st[(size_t)i];
     }
-    for (int i = 0; i < n && i < desc_cap; ++i) desc[i] = c->fdesc[(size_t)i].c_str();
+    for (int i = 0; i < n && i < desc_cap; ++i) desc[i] = q0.fdesc[(size_t)i].c_str();
     return n;
 }
 
 const char* rdmi_path_info(rdmi_ctx* c) {
     static thread_local std::string s;
     if (!c) return "";
-    s = (c->fused_ok && c->use_fused && !c->debug_taps) ? "fused: workgroup-resident U-Net, " + std::to_string(c->fprog.size()) + " ops, " + std::to_string(c->fused_lds) + " B LDS"
-                                                        : "layers: " + std::to_string(c->ops.size()) + " launches" + (c->fused_ok ? "" : " (fused unavailable: " + c->fused_why + ")");
+    if (c->fused_ready() && c->use_fused && !c->debug_taps) {
+        s = "fused: workgroup-resident U-Net, " + std::to_string(c->progs[0].fprog.size()) + " ops, " + std::to_string(c->progs[0].fused_lds) + " B LDS";
+        for (size_t i = 1; i < c->progs.size(); ++i)
+            s += c->progs[i].ok ? "; S=" + std::to_string(c->progs[i].S) + " samples/workgroup from batch " + std::to_string(c->s_min_wg * c->progs[i].S) + " (" + std::to_string(c->progs[i].fprog.size()) + " ops)"
+                                : "; S=" + std::to_string(c->progs[i].S) + " unavailable (" + c->progs[i].why + ")";
+    } else {
+        s = "layers: " + std::to_string(c->ops.size()) + " launches" + (c->fused_ready() ? "" : " (fused unavailable: " + (c->progs.empty() ? std::string("not built") : c->progs[0].why) + ")");
+    }
     return s.c_str();
 }
 
@@ -1365,6 +1535,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         train_registry().erase(c);
         delete T;
     }
+    for (auto& q : c->progs) for (void* p : {(void*)q.d_fprog, (void*)q.d_ftabs, (void*)q.d_spill}) if (p) hipFree(p);
     void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }

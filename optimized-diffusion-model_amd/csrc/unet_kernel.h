@@ -42,7 +42,7 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
-enum { FOP_GATHER = 0, FOP_STORE = 1, FOP_GN = 2, FOP_CONV = 3, FOP_ATTN = 4 };
+enum { FOP_GATHER = 0, FOP_STORE = 1, FOP_GN = 2, FOP_CONV = 3, FOP_ATTN = 4, FOP_LOADTAB = 5 };
 
 struct FPhase {            // one K-phase of a contraction: A rows come from an LDS tensor through a row table
     int lds_off;           // byte offset of the A tensor in LDS
@@ -87,6 +87,11 @@ struct FOp {
     // parked in LDS, one extra barrier, then the normalised values are written to gn_off.  gn_raw: the raw output is ALSO
     // written to dst (the residual / shortcut of the next block still needs it).  gamma / beta / eps / inv_cnt as for GN.
     int gn_off, gn_rs, gn_act, gn_raw, gn_slot_off, gn_nslots;
+    // Samples per workgroup (UnetArgs::S > 1, large batches): an op either belongs to ONE sample slot (samp >= 0: the
+    // full-resolution sections run per sample, one after the other, in the same LDS) or covers ALL S samples at once
+    // (samp < 0: the low-resolution section -- tensors are [S * hw rows][C], row r belongs to sample r >> hw_shift, so every
+    // streamed weight fragment feeds S samples).  hw_shift = log2(rows per sample) for multi-sample ops (hw is 4 or 16).
+    int samp, hw_shift;
 };
 
 struct UnetArgs {
@@ -99,6 +104,7 @@ struct UnetArgs {
     const float* x_in; int x_mod;                 // network input [x_mod or NB][HW][channels] (GATHER with a_off == -2)
     float* out;                                   // network output [NB][HW][channels]   (CONV dst_kind 2, g_out null)
     int NB;
+    int S;                                        // samples per workgroup: workgroup b owns samples b*S .. b*S+S-1 (clamped to NB-1)
     int dbg;                                      // diagnostic ablations (0 in production; results are wrong when set): bit 2 skips GN
                                                   // bodies, bit 3 CONV, bit 4 ATTN, bit 5 GATHER/STORE, bits 6/7 GN statistics / apply,
                                                   // bit 8 conv epilogues, bit 9 conv main loops (scripts/gpu_ablate.py)
@@ -129,11 +135,17 @@ __device__ __forceinline__ OpW opw_load(const FOp* op, int lane) {
 
 __device__ __forceinline__ float* lds_f(int off) { return reinterpret_cast<float*>(rdmi_lds + off); }
 
-__device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int n, int tid) {
-    struct { int C, rows, dst_off, dst_rs, CA, CB, a_off, a_rs, a_hw, a_mod, a_map_off, b_off, b_rs; const float* a_g; const float* b_g; } o;
+// sample index of row `row` of an op: slot `samp` for single-sample ops, row >> hw_shift for multi-sample ops; the global
+// sample number is clamped to the batch (a tail workgroup recomputes the last sample in its unused slots)
+__device__ __forceinline__ int samp_of(int samp, int hw_shift, int row) { return samp >= 0 ? samp : (row >> hw_shift); }
+
+template <bool MS>
+__device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int n0, int tid) {
+    struct { int C, rows, dst_off, dst_rs, CA, CB, a_off, a_rs, a_hw, a_mod, a_map_off, b_off, b_rs, samp, hw_shift; const float* a_g; const float* b_g; } o;
     o.C = OPI(w, C); o.rows = OPI(w, rows); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.CA = OPI(w, CA); o.CB = OPI(w, CB);
     o.a_off = OPI(w, a_off); o.a_rs = OPI(w, a_rs); o.a_hw = OPI(w, a_hw); o.a_mod = OPI(w, a_mod); o.a_map_off = OPI(w, a_map_off);
     o.b_off = OPI(w, b_off); o.b_rs = OPI(w, b_rs); o.a_g = OPP(w, const float, a_g); o.b_g = OPP(w, const float, b_g);
+    o.samp = MS ? OPI(w, samp) : 0; o.hw_shift = MS ? OPI(w, hw_shift) : 0;
     const int Cd = o.C;                               // padded total channels (multiple of 4)
     const int c4n = Cd >> 2;
     const int total = o.rows * c4n;
@@ -144,15 +156,19 @@ __device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int 
     const bool from_x = o.a_off == -2;
     const float* ag = from_x ? u.x_in : o.a_g;
     const int amod = from_x ? u.x_mod : o.a_mod;
-    const int nA = amod > 0 ? n % amod : n;
+    const int hw = o.samp >= 0 ? o.rows : (1 << o.hw_shift);          // destination rows per sample
     for (int i = tid; i < total; i += UW_THREADS) {
         const int c = c4 << 2;
+        const int sl = samp_of(o.samp, o.hw_shift, row);             // sample slot and pixel of this destination row
+        const int px = o.samp >= 0 ? row : row - (sl << o.hw_shift);
+        const int n = min(n0 + sl, u.NB - 1);
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
         if (c < o.CA) {
-            const int srow = map ? map[row] : row;
-            if (o.a_off >= 0) {
-                val = *reinterpret_cast<const f32x4*>(lds_f(o.a_off) + (size_t)srow * o.a_rs + c);
+            const int srow = map ? map[px] : px;
+            if (o.a_off >= 0) {                                      // LDS source: multi-sample tensors hold a_hw rows per sample
+                val = *reinterpret_cast<const f32x4*>(lds_f(o.a_off) + (size_t)((o.samp >= 0 ? 0 : sl * o.a_hw) + srow) * o.a_rs + c);
             } else {
+                const int nA = amod > 0 ? n % amod : n;
                 const float* p = ag + ((size_t)nA * o.a_hw + srow) * o.CA + c;
                 if ((o.CA & 3) == 0) val = ldg4(p);
                 else
@@ -161,7 +177,7 @@ __device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int 
             }
         } else if (c < o.CA + o.CB) {
             if (o.b_off >= 0) val = *reinterpret_cast<const f32x4*>(lds_f(o.b_off) + (size_t)row * o.b_rs + (c - o.CA));
-            else val = ldg4(o.b_g + ((size_t)n * o.rows + row) * o.CB + (c - o.CA));
+            else val = ldg4(o.b_g + ((size_t)n * hw + px) * o.CB + (c - o.CA));
         }
         *reinterpret_cast<f32x4*>(dst + (size_t)row * o.dst_rs + c) = val;
         row += dpv; c4 += dc4;
@@ -169,17 +185,22 @@ __device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int 
     }
 }
 
-__device__ __forceinline__ void fop_store(const OpW& w, int n, int tid) {
-    struct { int C, rows, dst_off, dst_rs; float* g_out; } o;
+template <bool MS>
+__device__ __forceinline__ void fop_store(const OpW& w, const UnetArgs& u, int n0, int tid) {
+    struct { int C, rows, dst_off, dst_rs, samp, hw_shift; float* g_out; } o;
     o.C = OPI(w, C); o.rows = OPI(w, rows); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.g_out = OPP(w, float, g_out);
+    o.samp = MS ? OPI(w, samp) : 0; o.hw_shift = MS ? OPI(w, hw_shift) : 0;
     const int c4n = o.C >> 2;
     const int total = o.rows * c4n;
     const float* src = lds_f(o.dst_off);
-    float* g = o.g_out + (size_t)n * o.rows * o.C;
+    const int hw = o.samp >= 0 ? o.rows : (1 << o.hw_shift);
     const int dpv = UW_THREADS / c4n, dc4 = UW_THREADS - dpv * c4n;
     int row = tid / c4n, c4 = tid - row * c4n;
     for (int i = tid; i < total; i += UW_THREADS) {
-        stg4(g + (size_t)row * o.C + (c4 << 2), *reinterpret_cast<const f32x4*>(src + (size_t)row * o.dst_rs + (c4 << 2)));
+        const int sl = samp_of(o.samp, o.hw_shift, row);
+        const int px = o.samp >= 0 ? row : row - (sl << o.hw_shift);
+        const int n = min(n0 + sl, u.NB - 1);        // duplicate slots of a tail workgroup store the same values to the same place
+        stg4(o.g_out + ((size_t)n * hw + px) * o.C + (c4 << 2), *reinterpret_cast<const f32x4*>(src + (size_t)row * o.dst_rs + (c4 << 2)));
         row += dpv; c4 += dc4;
         if (c4 >= c4n) { c4 -= c4n; ++row; }
     }
@@ -199,23 +220,30 @@ __device__ __forceinline__ float group_sum_rt(float v, int logT, int lane) {
 // group's values held in REGISTERS between the passes (one LDS read per element), T lanes per group reduced by
 // xor-shuffles; the affine parameters of this work-item's fixed channel quad are prefetched by the caller one op
 // ahead (pgm/pbt) so their global latency never sits on the op-transition path.
+template <bool MS>
 __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4 pgm, f32x4 pbt, int dbg = 0) {
-    float* X = lds_f(OPI(w, dst_off));
+    float* X0 = lds_f(OPI(w, dst_off));
     const int src_off = OPI(w, src_off);
-    const float* S = src_off >= 0 ? lds_f(src_off) : X;
+    const float* S0 = src_off >= 0 ? lds_f(src_off) : X0;
     const int srs = src_off >= 0 ? OPI(w, src_rs) : OPI(w, dst_rs);
-    const int o_C = OPI(w, C), Cg = OPI(w, Cg), rs = OPI(w, dst_rs), o_rows = OPI(w, rows), o_act = OPI(w, act);
+    const int o_C = OPI(w, C), Cg = OPI(w, Cg), rs = OPI(w, dst_rs), o_act = OPI(w, act);
+    // multi-sample ops (samp < 0): the tensor is ns samples of hw rows; statistics are per sample ([ns][2 * G] in `stat`)
+    const int o_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
+    const int o_rows = o_samp >= 0 ? OPI(w, rows) : (1 << hw_shift);
+    const int ns = o_samp >= 0 ? 1 : (OPI(w, rows) >> hw_shift);
+    const int o_G = OPI(w, G);
     const float o_eps = OPF(w, eps);
     const int logT = OPI(w, logT), T = 1 << logT;     // 16 or 32 lanes per group
     const int g = tid >> logT, sub = tid & (T - 1);
     const float inv_cnt = OPF(w, inv_cnt);
     const int mg_c4n = OPI(w, magic_c4n), mg_Cg = OPI(w, magic_Cg);
-    const float* base = S + g * Cg;
     // this lane's share of the group: rows sub, sub+T, ... (<= 6 rows for 96 pixels at T = 16), Cg <= 8 channels
     constexpr int MAXR = 6;
+    if (!(dbg & 64)) {
+    for (int sm = 0; sm < ns; ++sm) {
+    const float* base = S0 + (size_t)sm * o_rows * srs + g * Cg;
     f32x4 v0[MAXR], v1[MAXR];
     float sum = 0.f;
-    if (!(dbg & 64)) {
     // Branch-free over rows: every lane loads its (clamped) rows back to back -- all reads in flight before the first
     // wait -- and rows beyond the tensor / channels beyond the group are masked out of the sums.  Only the group width
     // (Cg = 4, 8: one or two 16-byte reads; Cg = 6: three 8-byte reads, groups start at 8-byte boundaries) branches,
@@ -253,7 +281,8 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
         sq += rw[k] * q;
     }
     sq = group_sum_rt(sq, logT, tid & 63);
-    if (sub == 0) { stat[2 * g] = mean; stat[2 * g + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
+    if (sub == 0) { stat[(sm * o_G + g) * 2] = mean; stat[(sm * o_G + g) * 2 + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
+    }
     }
     // fixed channel quad per work-item: rows advance by rstep; work-items beyond rstep*c4n idle (C = 192)
     const int c4n = o_C >> 2;
@@ -262,16 +291,20 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
     const bool active = r0 < rstep;
     lds_barrier();
     if (active && !(dbg & 128)) {
-        f32x4 mu, rstd;
-        for (int j = 0; j < 4; ++j) { const int gg = ((c + j) * mg_Cg) >> 16; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
-        for (int row = r0; row < o_rows; row += rstep) {
-            float* p = X + (size_t)row * rs + c;
-            f32x4 val = *reinterpret_cast<const f32x4*>(S + (size_t)row * srs + c);
-            for (int j = 0; j < 4; ++j) {
-                const float y = (val[j] - mu[j]) * rstd[j] + pbt[j];
-                val[j] = o_act ? silu_f(y) : y;
+        for (int sm = 0; sm < ns; ++sm) {
+            float* X = X0 + (size_t)sm * o_rows * rs;
+            const float* S = S0 + (size_t)sm * o_rows * srs;
+            f32x4 mu, rstd;
+            for (int j = 0; j < 4; ++j) { const int gg = sm * o_G + (((c + j) * mg_Cg) >> 16); mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
+            for (int row = r0; row < o_rows; row += rstep) {
+                float* p = X + (size_t)row * rs + c;
+                f32x4 val = *reinterpret_cast<const f32x4*>(S + (size_t)row * srs + c);
+                for (int j = 0; j < 4; ++j) {
+                    const float y = (val[j] - mu[j]) * rstd[j] + pbt[j];
+                    val[j] = o_act ? silu_f(y) : y;
+                }
+                *reinterpret_cast<f32x4*>(p) = val;
             }
-            *reinterpret_cast<f32x4*>(p) = val;
         }
     }
 }
@@ -404,7 +437,9 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
 // so LDS stores stay ds_write and global stores stay global_store (a merged pointer would degrade both to flat_store).
 // Returns true when the op carries a fused GroupNorm: acc[] then holds the finished raw outputs (bias, temb, residual, scale
 // applied), this wave's partial sums are parked in LDS, and the caller runs fconv_gn_apply after a workgroup barrier.
-__device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n, int mt0, int WM, int nt, int nmt, int lane, float add, f32x4 (&acc)[4]) {
+template <bool MS>
+__device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n0, int mt0, int WM, int nt, int nmt, int lane, float add, const float (&dadd)[4],
+                                          f32x4 (&acc)[4], float (&ps1)[4], float (&ps2)[4]) {
     const int lrow = lane & 15, kq = lane >> 4;
     const int o_rows = OPI(w, rows), o_Cout = OPI(w, Cout);
     const int o_resid = OPI(w, resid_off), o_resid_rs = OPI(w, resid_rs);
@@ -459,6 +494,7 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
     const int gn_off = o_kind == 0 ? OPI(w, gn_off) : -1;
     const bool write_raw = gn_off < 0 || OPI(w, gn_raw) != 0;
     float* const g_dst = OPP(w, float, g_out) ? OPP(w, float, g_out) : u.out;
+    const int OPI_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
     if (col < o_Cout) {
         if (o_resid >= 0) {
             const float* resp = lds_f(o_resid);
@@ -474,13 +510,13 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
             for (int i = 0; i < 4; ++i)
                 if (i < nmt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][r] = (acc[i][r] + add + rv[i][r]) * o_scale;
+                    for (int r = 0; r < 4; ++r) acc[i][r] = (acc[i][r] + (add + dadd[i]) + rv[i][r]) * o_scale;
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < nmt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][r] = (acc[i][r] + add + 0.f) * o_scale;
+                    for (int r = 0; r < 4; ++r) acc[i][r] = (acc[i][r] + (add + dadd[i]) + 0.f) * o_scale;
         }
         if (o_kind == 0) {
             if (write_raw) {
@@ -500,7 +536,7 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
                     }
             }
         } else {
-            float* gp = g_dst + (size_t)n * o_rows * o_Cout + col;
+            float* gp = g_dst + (size_t)min(n0 + max(OPI_samp, 0), u.NB - 1) * o_rows * o_Cout + col;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < nmt) {
@@ -517,16 +553,20 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
         }
     }
     if (gn_off < 0) return false;
-    // ---- fused GroupNorm, part 1: this wave's partial (sum, sum of squares) of every 4-channel group of its column tile.
-    // Lane (lrow, kq) holds rows kq*4..+3 of each tile for column lrow: sum over its rows, then over the quad's 4 columns;
-    // the quad leader parks the pair in slot (wm*4 + kq) of the group.  Slots are summed in a fixed order by the readers
-    // (no atomics: results are run-to-run identical).
+    // ---- fused GroupNorm, part 1: partial (sum, sum of squares) of every 4-channel group of this wave's column tile.
+    // Lane (lrow, kq) holds rows kq*4..+3 of each tile for column lrow: sum over its rows, then over the quad's 4 columns.
+    //  * single-sample op: the tiles' partials are added and the quad leader parks the pair in slot (wm*4 + kq) of the group;
+    //  * multi-sample op, 16 rows per sample: a tile IS a sample -- one slot per (sample, group, kq);
+    //  * multi-sample op, 4 rows per sample: the lane's four rows ARE a sample -- the quad sum is already the whole group
+    //    statistic and stays in registers (ps1 / ps2).
+    // Slots are summed in a fixed order by the readers (no atomics: results are run-to-run identical).
     {
         float* const slots = lds_f(OPI(w, gn_slot_off));
         const int nslots = OPI(w, gn_nslots);
-        float s1 = 0.f, s2 = 0.f;
+        const int G4 = o_Cout >> 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            float s1 = 0.f, s2 = 0.f;
             if (i < nmt) {
                 const int row0 = (mt0 + i * WM) * 16 + kq * 4;
 #pragma unroll
@@ -535,10 +575,25 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
                     s1 += v; s2 += v * v;
                 }
             }
-        s1 = quad_sum(s1); s2 = quad_sum(s2);
-        if ((lrow & 3) == 0) {
-            float* slot = slots + ((size_t)(col >> 2) * nslots + ((mt0 % WM) * 4 + kq)) * 2;
-            slot[0] = s1; slot[1] = s2;
+            ps1[i] = s1; ps2[i] = s2;
+        }
+        if (OPI_samp >= 0) {                               // one sample: add the tiles, then one quad reduction
+            const float t1 = quad_sum((ps1[0] + ps1[1]) + (ps1[2] + ps1[3])), t2 = quad_sum((ps2[0] + ps2[1]) + (ps2[2] + ps2[3]));
+            if ((lrow & 3) == 0) {
+                float* slot = slots + ((size_t)(col >> 2) * nslots + ((mt0 % WM) * 4 + kq)) * 2;
+                slot[0] = t1; slot[1] = t2;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ps1[i] = quad_sum(ps1[i]); ps2[i] = quad_sum(ps2[i]); }
+        }
+        if (OPI_samp < 0 && hw_shift == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nmt && (lrow & 3) == 0) {
+                    float* slot = slots + ((size_t)((mt0 + i * WM) * G4 + (col >> 2)) * 4 + kq) * 2;
+                    slot[0] = ps1[i]; slot[1] = ps2[i];
+                }
         }
     }
     return true;
@@ -546,25 +601,42 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
 
 // fused GroupNorm, part 2 (after the workgroup barrier): every lane re-reduces its column's group from the parked partials,
 // normalises the values it still holds in registers, applies the affine map (+SiLU) and writes the result to gn_off.
-__device__ __forceinline__ void fconv_gn_apply(const OpW& w, int mt0, int WM, int nt, int nmt, int lane, float gmul, float gadd, const f32x4 (&acc)[4]) {
+template <bool MS>
+__device__ __forceinline__ void fconv_gn_apply(const OpW& w, int mt0, int WM, int nt, int nmt, int lane, float gmul, float gadd, const f32x4 (&acc)[4],
+                                               const float (&ps1)[4], const float (&ps2)[4]) {
     const int lrow = lane & 15, kq = lane >> 4;
     const int o_rows = OPI(w, rows), o_Cout = OPI(w, Cout), nslots = OPI(w, gn_nslots);
+    const int o_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
     const int col = nt * 16 + lrow;
-    const float* slot = lds_f(OPI(w, gn_slot_off)) + (size_t)(min(col, o_Cout - 1) >> 2) * nslots * 2;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nslots; k += 2) {            // nslots is a multiple of 4
-        const f32x4 p = *reinterpret_cast<const f32x4*>(slot + 2 * k);
-        s1 += p[0]; s2 += p[1]; s1 += p[2]; s2 += p[3];
-    }
-    const float inv_cnt = OPF(w, inv_cnt);
-    const float mean = s1 * inv_cnt;
-    const float var = fmaxf(s2 * inv_cnt - mean * mean, 0.f);
-    const float rstd = (1.0f / sqrtf(var + OPF(w, eps))) * gmul;
+    const int gcol = min(col, o_Cout - 1) >> 2, G4 = o_Cout >> 2;
+    const float* slots = lds_f(OPI(w, gn_slot_off));
+    const float inv_cnt = OPF(w, inv_cnt), eps = OPF(w, eps);
     const int act = OPI(w, gn_act), rs = OPI(w, gn_rs);
     float* dstp = lds_f(OPI(w, gn_off));
+    float mean = 0.f, rstd = 0.f;
+    if (o_samp >= 0) {                       // one sample: the same statistics for every tile
+        const float* slot = slots + (size_t)gcol * nslots * 2;
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < nslots; k += 2) {            // nslots is a multiple of 4
+            const f32x4 p = *reinterpret_cast<const f32x4*>(slot + 2 * k);
+            s1 += p[0]; s2 += p[1]; s1 += p[2]; s2 += p[3];
+        }
+        mean = s1 * inv_cnt;
+        rstd = (1.0f / sqrtf(fmaxf(s2 * inv_cnt - mean * mean, 0.f) + eps)) * gmul;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < nmt) {
+            if (o_samp < 0) {
+                float s1, s2;
+                if (hw_shift == 4) {
+                    const float* slot = slots + (size_t)((mt0 + i * WM) * G4 + gcol) * 8;
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(slot), q = *reinterpret_cast<const f32x4*>(slot + 4);
+                    s1 = (p[0] + p[2]) + (q[0] + q[2]); s2 = (p[1] + p[3]) + (q[1] + q[3]);
+                } else { s1 = ps1[i]; s2 = ps2[i]; }
+                mean = s1 * inv_cnt;
+                rstd = (1.0f / sqrtf(fmaxf(s2 * inv_cnt - mean * mean, 0.f) + eps)) * gmul;
+            }
             const int row0 = (mt0 + i * WM) * 16 + kq * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -574,8 +646,8 @@ __device__ __forceinline__ void fconv_gn_apply(const OpW& w, int mt0, int WM, in
         }
 }
 
-template <bool DIAG>
-__device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n, int wave, int lane, long long* fine) {
+template <bool DIAG, bool MS>
+__device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0, int wave, int lane, long long* fine) {
     const int ntiles = OPI(w, Cout_pad) >> 4, mtiles = OPI(w, mtiles);
     const int lWN = (ntiles >= 8 && (ntiles & 7) == 0) ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // log2 of waves along N
     const int WN = 1 << lWN, WM = UW_WAVES >> lWN, lWM = 3 - lWN;
@@ -583,7 +655,10 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
     const int o_Cout = OPI(w, Cout), o_dense = OPI(w, dense_off);
     const float* o_bias = OPP(w, const float, bias); const float* o_bias2 = OPP(w, const float, bias2);
     const bool fused_gn = OPI(w, dst_kind) == 0 && OPI(w, gn_off) >= 0;      // host guarantees: then every wave has at most one pass below
+    const int o_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
+    const float* dense_base = u.dense + (size_t)o_dense;
     f32x4 acc[4];
+    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
     float gmul = 1.f, gadd = 0.f;
     int k_mt0 = 0, k_nt = 0, k_nmt = 0;
     for (int nt = wn; nt < ntiles; nt += WN) {
@@ -593,13 +668,27 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
         if (col < o_Cout) {
             add = ldg1(o_bias + col);
             if (o_bias2) add += ldg1(o_bias2 + col);
-            if (o_dense >= 0) add += ldg1(u.dense + (size_t)n * u.dense_stride + o_dense + col);
             if (fused_gn) { gmul = ldg1(OPP(w, const float, gamma) + col); gadd = ldg1(OPP(w, const float, beta) + col); }
         }
         // this wave's row tiles wm, wm+WM, ... in groups of at most 4 (only NMT 1..4 are instantiated)
         for (int mt0 = wm; mt0 < mtiles; mt0 += 4 * WM) {
             const int left = (mtiles - mt0 + WM - 1) >> lWM;
             const int nmt = left >= 4 ? 4 : left;
+            // Dense_0(SiLU(temb)) of the sample each row tile belongs to (this lane's rows kq*4..+3 of a tile are one sample)
+            float dadd[4] = {0.f, 0.f, 0.f, 0.f};
+            if (o_dense >= 0 && col < o_Cout) {
+                if (o_samp >= 0) {
+                    const float dv = ldg1(dense_base + (size_t)min(n0 + o_samp, u.NB - 1) * u.dense_stride + col);
+                    dadd[0] = dadd[1] = dadd[2] = dadd[3] = dv;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < nmt) {
+                            const int sl = ((mt0 + i * WM) * 16 + (lane >> 4) * 4) >> hw_shift;
+                            dadd[i] = ldg1(dense_base + (size_t)min(n0 + sl, u.NB - 1) * u.dense_stride + col);
+                        }
+                }
+            }
             switch (nmt) {
                 case 1:
                     if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_main<DIAG, 1, UW_PF_M4, true>(w, u, mt0, WM, nt, lane, fine, acc);
@@ -618,14 +707,14 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n,
                 default: break;
             }
             if (DIAG && (u.dbg & 256)) continue;                 // ablation: no epilogue
-            fconv_epi(w, u, n, mt0, WM, nt, nmt, lane, add, acc);
+            fconv_epi<MS>(w, u, n0, mt0, WM, nt, nmt, lane, add, dadd, acc, ps1, ps2);
             k_mt0 = mt0; k_nt = nt; k_nmt = nmt;
             if (DIAG && fine) fine[5] = clock64();
         }
     }
     if (fused_gn) {
         lds_barrier();
-        if (k_nmt > 0) fconv_gn_apply(w, k_mt0, WM, k_nt, k_nmt, lane, gmul, gadd, acc);
+        if (k_nmt > 0) fconv_gn_apply<MS>(w, k_mt0, WM, k_nt, k_nmt, lane, gmul, gadd, acc, ps1, ps2);
     }
 }
 
@@ -723,11 +812,13 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
 
 // DIAG = true is the diagnostic build of the same kernel (per-op cycle stamps, per-op-kind ablation); the production
 // instantiation compiles all of that away -- the interpreter has to stay inside the 64 KiB instruction cache.
-template <bool DIAG>
+// MS = true: the program may hold multi-sample ops (S > 1 samples per workgroup); MS = false compiles every trace of that away
+// (the S = 1 program that serves B <= 128 with guidance keeps its leaner code).
+template <bool DIAG, bool MS = false>
 __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.x;
+    const int n = MS ? blockIdx.x * u.S : blockIdx.x;                       // first sample of this workgroup (ops add their slot)
     // tables + zero row
     {
         const int nw = u.tab_bytes >> 2;
@@ -760,11 +851,18 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         if (DIAG && fine) fine[3] = clock64();
         const int skip = (DIAG && u.dbg) ? ((kind == FOP_GN ? 4 : kind == FOP_CONV ? 8 : kind == FOP_ATTN ? 16 : 32) & u.dbg) : 0;
         switch (skip ? -1 : kind) {
-            case FOP_GATHER: fop_gather(cur, u, n, tid); break;
-            case FOP_STORE: fop_store(cur, n, tid); break;
-            case FOP_GN: fop_gn(cur, stat, tid, pgm, pbt, DIAG ? u.dbg : 0); break;
-            case FOP_CONV: fop_conv<DIAG>(cur, u, n, wave, lane, fine); break;
+            case FOP_GATHER: fop_gather<MS>(cur, u, n, tid); break;
+            case FOP_STORE: fop_store<MS>(cur, u, n, tid); break;
+            case FOP_GN: fop_gn<MS>(cur, stat, tid, pgm, pbt, DIAG ? u.dbg : 0); break;
+            case FOP_CONV: fop_conv<DIAG, MS>(cur, u, n, wave, lane, fine); break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
+            case FOP_LOADTAB: {      // row tables of the multi-sample section: global -> their LDS block
+                const int* src = OPP(cur, const int, a_g);
+                int* dst = reinterpret_cast<int*>(rdmi_lds + OPI(cur, dst_off));
+                const int nw = OPI(cur, rows) >> 2;
+                for (int i = tid; i < nw; i += UW_THREADS) dst[i] = src[i];
+                break;
+            }
             default: break;
         }
         // ops that stored to global memory (skip spills, the network output) end with the full barrier: their stores must have

@@ -57,6 +57,27 @@ def test_forward_golden_both_plans(env, golden, path):
     np.testing.assert_allclose(s.numpy(), g['score'][idx], rtol=0, atol=5e-5)
 
 
+def test_multi_sample_programs(env, golden):
+    """Large-batch programs (S = 2 / 4 samples per workgroup: the low-resolution half of the network runs for all S samples at
+    once) against the reference's recorded forward.  RDMI_S_MIN_WG=1 lowers the batch threshold so that 2 samples select S=2
+    and 5 samples select S=4 with a ragged last workgroup (one real sample, three clamped slots)."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    g = golden('forward_9x9.npz')
+    os.environ['RDMI_S_MIN_WG'] = '1'
+    try:
+        model, _, _ = env['ge'].make_model('cpu')
+        sde = sde_lib.RVESDE(0.01, 5, N=1000)
+        for idx in ([6, 2], [0, 1, 2, 3, 7]):
+            with torch.no_grad():
+                s = mutils.get_score_fn(sde, model)(T(g['x'][idx]), T(g['t'][idx]), class_labels=T(g['labels'][idx]))
+            np.testing.assert_allclose(s.numpy(), g['score'][idx], rtol=0, atol=5e-5)
+        info = model._ctx[('cpu', 9, 9)].path_info()
+        assert 'S=2 samples/workgroup from batch 2' in info and 'S=4 samples/workgroup from batch 4' in info, info
+    finally:
+        os.environ.pop('RDMI_S_MIN_WG', None)
+
+
 def test_layer_plan_intermediate_activations(env, golden):
     """Every recorded reference activation (21 taps) against the layer plan's tensors."""
     from rdmi import sde_lib

@@ -327,6 +327,48 @@ def test_large_batch_many_workgroups(env):
     assert np.isfinite(s).all()
 
 
+def test_multi_sample_programs_large_batch(env):
+    """Batches of >= 512 / >= 1024 model samples select the S = 2 / S = 4 samples-per-workgroup programs (the low-resolution half
+    of the U-Net runs for S samples at once): B = 601 with guidance (1202 forwards: S = 4, ragged last workgroup), 700 plain
+    forwards (S = 2), against the oracle on samples from the first, middle and last workgroups; and the S programs agree with the
+    single-sample program on the whole batch."""
+    from oracle import rd_oracle as O
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    dev, model, params, ge = env['dev'], env['model'], env['params'], env['ge']
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    o = O.RVESDE(0.01, 5, N=1000)
+    g = torch.Generator().manual_seed(19)
+    B = 601
+    x = torch.rand(B, 1, 9, 9, generator=g); t = torch.rand(B, generator=g) * 0.99 + 0.01; lab = torch.rand(B, 1, generator=g)
+    w = torch.rand(B, generator=g)
+    with torch.no_grad():
+        cf = mutils.get_cf_score_fn(sde, model, lab.to(dev), w.to(dev))(x.to(dev), t.to(dev))
+    info = model._ctx[(str(dev), 9, 9)].path_info()
+    assert 'S=4 samples/workgroup from batch 1024' in info, info
+    idx = [0, 3, 299, 300, 598, 599, 600]
+    ref = O.cf_score_fn(params, o, x.numpy()[idx], t.numpy()[idx], lab.numpy()[idx], w.numpy()[idx])
+    np.testing.assert_allclose(cf.cpu().numpy()[idx], ref, rtol=0, atol=6e-4)           # |1+w|+|w| up to 3
+    B2 = 700
+    x2 = torch.rand(B2, 1, 9, 9, generator=g); t2 = torch.rand(B2, generator=g) * 0.99 + 0.01; lab2 = torch.rand(B2, 1, generator=g)
+    with torch.no_grad():
+        s2 = mutils.get_score_fn(sde, model)(x2.to(dev), t2.to(dev), class_labels=lab2.to(dev))
+    idx2 = [0, 1, 349, 350, 698, 699]
+    ref2 = O.score_fn(params, o, x2.numpy()[idx2], t2.numpy()[idx2], lab2.numpy()[idx2])
+    np.testing.assert_allclose(s2.cpu().numpy()[idx2], ref2, rtol=0, atol=2e-4)
+    os.environ['RDMI_S'] = '1'
+    try:
+        m1, _, _ = ge.make_model(dev)
+        with torch.no_grad():
+            s1 = mutils.get_score_fn(sde, m1)(x2.to(dev), t2.to(dev), class_labels=lab2.to(dev))
+            cf1 = mutils.get_cf_score_fn(sde, m1, lab.to(dev), w.to(dev))(x.to(dev), t.to(dev))
+    finally:
+        os.environ.pop('RDMI_S', None)
+    assert 'S=' not in m1._ctx[(str(dev), 9, 9)].path_info()
+    np.testing.assert_allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=3e-5)
+    np.testing.assert_allclose(cf.cpu().numpy(), cf1.cpu().numpy(), rtol=0, atol=1e-4)
+
+
 def test_eval_loss_step_matches_reference(env, golden):
     """The evaluation step of losses.get_step_fn on the GPU against the reference's recorded loss value."""
     from tests.test_emu_parity import _eval_loss
