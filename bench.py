@@ -248,8 +248,30 @@ def variants(ge, dev, args, labels):
                      'plan': model._ctx[(str(dev), 9, 9)].path_info(),
                      'whole_path_frac_of_fp32_peak': (Bv / per_1000) * 2 * 999 * GFLOP_PER_FORWARD / 1e3 / PEAK_FP32_MFMA_TFLOPS}
         del model
+    out['cifar_b16'] = cifar_variant(ge, dev, 16)
     out['train_b128'] = train_variant(ge, dev, 128)
     return out
+
+
+def cifar_variant(ge, dev, B, N=9):
+    """BASELINE config #5: the CIFAR-shape NCSN++ (32x32x3, nf=128, ch_mult [1,2,2,2], 8 res blocks, attention at 16x16, 104.7 M
+    parameters, 36.9 GFLOP per sample-forward) through the tiled plan, fp32, guidance path on (2B forwards per update).  A
+    1000-scale trajectory of this model is ~25 s per batch: N-1 = 8 updates are timed and scaled per update."""
+    from rdmi import sampling, sde_lib
+    GF = 36.912                                            # 18.456 GMAC per sample-forward (SURVEY 8d)
+    model, cfg, _ = ge.make_cifar_model(dev, num_scales=N)
+    sde = sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=N)
+    lab = torch.zeros(B, 1, device=dev)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 3, 32, 32), 1e-5, dev)
+    fn(model, weight=0.0, class_labels=lab)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    x, nfe = fn(model, weight=0.0, class_labels=lab)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (N - 1)
+    assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
+    tf = 2 * B * GF / dt / 1e3
+    return {'value': B / (dt * 999), 'unit': 'trajectories/s (scaled to 1000 scales from %d timed updates)' % (N - 1), 'batch': B,
+            'ms_per_update': 1e3 * dt, 'dtype': 'f32', 'tflops': tf, 'frac': tf / PEAK_FP32_MFMA_TFLOPS,
+            'plan': model._ctx[(str(dev), 32, 32)].path_info()}
 
 
 def train_variant(ge, dev, B, steps=10):

@@ -23,6 +23,7 @@
 #include "bwd_kernels.h"
 #include "opt_kernels.h"
 #include "ode_kernels.h"
+#include "tiled_kernels.h"
 
 namespace {
 
@@ -158,6 +159,26 @@ struct rdmi_ctx {
         FOp* d_fprog = nullptr; short* d_ftabs = nullptr; float* d_spill = nullptr; size_t spill_per_sample = 0;
         UnetArgs fargs{}; size_t fused_lds = 0;
     };
+    // tiled plan (shapes whose samples do not fit one workgroup: csrc/tiled_kernels.h)
+    struct TLaunch {
+        int kind = 0;                 // 0 conv, 1 GroupNorm statistics, 2 batched GEMM, 3 softmax, 4 transpose
+        std::string name;
+        TConvArgs conv{}; int nmt = 4;
+        const float *sA = nullptr, *sB = nullptr; int CA = 0, CB = 0, HW = 0, G = 0; float* stats = nullptr;     // kind 1
+        BgemmArgs gemm{};                                                                                       // kind 2
+        float* sm = nullptr; long rows_per_sample = 0; int L = 0;                                               // kind 3
+        const float* tsrc = nullptr; float* tdst = nullptr; int tL = 0, tC = 0, tld = 0, tc0 = 0;               // kind 4
+        // per-sample workspace offsets (floats) of the operands, resolved to pointers by finish_tiled_plan: NONE = absent, XIN = the NHWC input copy
+        static constexpr size_t NONE = (size_t)-1, XIN = (size_t)-2;
+        size_t oA = NONE, oB = NONE, oStats = NONE, oResid = NONE, oOut = NONE, oC = NONE; long dA = 0, dB = 0;   // dA/dB: interior deltas of GEMM operands
+        bool use_dense = false;
+        std::string p_gamma, p_beta, p_bias; size_t w_off = 0; size_t bias_arena = (size_t)-1;
+        bool in_is_x = false, out_is_final = false;
+        double flops_per_sample = 0;
+    };
+    bool tiled = false;
+    std::vector<TLaunch> tl;
+    float *t_ws = nullptr, *t_xin = nullptr, *t_out = nullptr; size_t t_ws_per_sample = 0;
     std::vector<FusedProg> progs;
     int s_min_wg = 256;                            // a program with S samples per workgroup is used from batch s_min_wg * S (RDMI_S_MIN_WG: tests)
     const FusedProg* pick(int NB) const {          // the program with the most samples per workgroup that still fills the chip
@@ -480,6 +501,210 @@ int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, in
     return b.add_conv(s1, err);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// tiled plan (csrc/tiled_kernels.h): NCSNpp.forward (RD/models/ncsnpp.py:226-354) as a list of launches over
+// HBM-resident NHWC tensors, for shapes beyond one workgroup per sample (the CIFAR-shape model of BASELINE config #5)
+// ------------------------------------------------------------------------------------------
+struct TiledBuilder {
+    rdmi_ctx* c; Builder& b;
+    size_t top = 0;                                   // floats per sample allocated so far
+    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; };
+    TT talloc(int C, int H, int W) { TT t; t.off = top; t.C = C; t.H = H; t.W = W; t.valid = true; top += ((size_t)C * H * W + 63) & ~(size_t)63; return t; }
+    static int pad32(int a) { return (a + 31) & ~31; }
+
+    size_t pack3x3(const std::string& pre, int cin, int cout) {
+        const int Kp = pad32(cin), Np = pad16(cout);
+        const size_t o = b.alloc_w((size_t)9 * Kp * Np);
+        b.job_pack(pre + ".weight", o, cin, cout, Kp, Np, 0, 9, (long)cin * 9, 9, 1);
+        return o;
+    }
+    size_t pack1x1(const std::string& pre, int cin, int cout) {
+        const int Kp = pad32(cin), Np = pad16(cout);
+        const size_t o = b.alloc_w((size_t)Kp * Np);
+        b.job_pack(pre + ".W", o, cin, cout, Kp, Np, 0, 1, 1, cout, 0);
+        return o;
+    }
+    TT stats(const std::string& name, const TT& A, const TT* B) {
+        const int C = A.C + (B ? B->C : 0), G = std::min(C / 4, 32);
+        TT st = talloc(2 * G, 1, 1);
+        rdmi_ctx::TLaunch l; l.kind = 1; l.name = name + ".stats";
+        l.oA = A.off; l.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; l.CA = A.C; l.CB = B ? B->C : 0; l.HW = A.H * A.W; l.G = G;
+        l.oStats = st.off;
+        c->tl.push_back(l);
+        return st;
+    }
+    // conv over concat(A, B) [optionally GroupNorm(+SiLU)'d with `st`], 3x3 (stride 1 pad 1 | stride 2 Downsample | nearest x2 Upsample) or 1x1
+    TT conv(const std::string& name, const TT& A, const TT* B, const TT* st, const std::string& gn, bool act, int ntap, int stride, bool up,
+            size_t w_off, int cout, const std::string& bias_param, size_t bias_arena, int dense_off, const TT* resid, float scale, bool final_out) {
+        TConvArgs a{};
+        a.CA = A.C; a.CB = B ? B->C : 0; a.Cv = pad32(a.CA + a.CB);
+        a.Ha = A.H; a.Wa = A.W; a.up = up ? 1 : 0; a.Hv = up ? 2 * A.H : A.H; a.Wv = up ? 2 * A.W : A.W;
+        a.stride = stride; a.ntap = ntap; a.pad_lo = (ntap == 9 && stride == 1) ? 1 : 0;
+        a.Ho = stride == 2 ? (a.Hv + 1 - 3) / 2 + 1 : a.Hv; a.Wo = stride == 2 ? (a.Wv + 1 - 3) / 2 + 1 : a.Wv;
+        a.TR = a.Wo >= 64 ? 1 : std::max(1, std::min(a.Ho, 64 / a.Wo));
+        if (st) { a.G = std::min((a.CA + a.CB) / 4, 32); a.Cg = (a.CA + a.CB) / a.G; a.act = act ? 1 : 0; }
+        a.dense_off = dense_off < 0 ? 0 : dense_off; a.dense_stride = c->dense_total;
+        a.out_scale = scale;
+        a.Cout = cout; a.Cout_pad = pad16(cout);
+        TT out = talloc(cout, a.Ho, a.Wo);
+        rdmi_ctx::TLaunch l; l.kind = 0; l.name = name; l.conv = a;
+        l.oA = A.off; l.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; l.oStats = st ? st->off : rdmi_ctx::TLaunch::NONE;
+        l.oResid = resid ? resid->off : rdmi_ctx::TLaunch::NONE; l.oOut = out.off;
+        l.nmt = (a.TR * a.Wo > 16) ? 4 : 1;
+        l.w_off = w_off; l.p_bias = bias_param; l.bias_arena = bias_arena;
+        if (st) { l.p_gamma = gn + ".weight"; l.p_beta = gn + ".bias"; }
+        l.out_is_final = final_out;
+        l.use_dense = dense_off >= 0;
+        l.flops_per_sample = 2.0 * a.Ho * a.Wo * cout * (double)ntap * (a.CA + a.CB);
+        c->tl.push_back(l);
+        return out;
+    }
+    TT resblock(const std::string& name, const TT& A, const TT* B, int cout, int dense_off) {
+        const int cin = A.C + (B ? B->C : 0);
+        const float rs2 = (float)(1.0 / std::sqrt(2.0));
+        TT st0 = stats(name + ".GroupNorm_0", A, B);
+        TT h1 = conv(name + ".Conv_0", A, B, &st0, name + ".GroupNorm_0", true, 9, 1, false, pack3x3(name + ".Conv_0", cin, cout), cout,
+                     name + ".Conv_0.bias", (size_t)-1, dense_off, nullptr, 1.f, false);
+        TT st1 = stats(name + ".GroupNorm_1", h1, nullptr);
+        const size_t w1 = pack3x3(name + ".Conv_1", cout, cout);
+        if (cin != cout) {
+            TT sc = conv(name + ".NIN_0", A, B, nullptr, "", false, 1, 1, false, pack1x1(name + ".NIN_0", cin, cout), cout, name + ".NIN_0.b", (size_t)-1, -1,
+                         nullptr, 1.f, false);
+            return conv(name + ".Conv_1", h1, nullptr, &st1, name + ".GroupNorm_1", true, 9, 1, false, w1, cout, name + ".Conv_1.bias", (size_t)-1, -1, &sc, rs2, false);
+        }
+        return conv(name + ".Conv_1", h1, nullptr, &st1, name + ".GroupNorm_1", true, 9, 1, false, w1, cout, name + ".Conv_1.bias", (size_t)-1, -1, &A, rs2, false);
+    }
+    // AttnBlockpp (RD/models/layerspp.py:67-96): GN -> q,k,v (one 1x1 conv, Cout = 3C) -> softmax(q k^T / sqrt(C)) v -> NIN_3 -> (x + h)/sqrt2
+    TT attn(const std::string& name, const TT& x) {
+        const int C = x.C, Lq = x.H * x.W;
+        if (C % 32 != 0 || Lq % 16 != 0) throw std::runtime_error("tiled attention needs C % 32 == 0 and H*W % 16 == 0");
+        TT st = stats(name + ".GroupNorm_0", x, nullptr);
+        const size_t o3 = b.alloc_w((size_t)3 * C * C);
+        for (int i = 0; i < 3; ++i) {
+            PackJob j{};
+            j.dst = reinterpret_cast<float*>(o3);
+            j.Cin = C; j.Cout = C; j.Kpad = C; j.Npad = 3 * C; j.n_off = i * C; j.ntap = 1; j.s_co = 1; j.s_ci = C; j.s_t = 0; j.kind = 0;
+            c->jobs.push_back(j);
+            c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
+        }
+        const size_t bq = b.alloc_w((size_t)3 * C);
+        for (int i = 0; i < 3; ++i) b.job_copy(name + ".NIN_" + std::to_string(i) + ".b", bq, C, i * C);
+        TT qkv = conv(name + ".qkv", x, nullptr, &st, name + ".GroupNorm_0", false, 1, 1, false, o3, 3 * C, "", bq, -1, nullptr, 1.f, false);
+        TT S = talloc(Lq, Lq, 1);                    // [L][L] scores / probabilities
+        TT Vt = talloc(C, Lq, 1);                    // [C][L]
+        TT O = talloc(C, x.H, x.W);
+        {
+            rdmi_ctx::TLaunch l; l.kind = 2; l.name = name + ".qk";
+            l.oA = qkv.off; l.oB = qkv.off; l.dB = C; l.oC = S.off;
+            l.gemm.sa = l.gemm.sb = (long)Lq * 3 * C; l.gemm.sc = (long)Lq * Lq; l.gemm.lda = l.gemm.ldb = 3 * C; l.gemm.ldc = Lq;
+            l.gemm.M = Lq; l.gemm.N = Lq; l.gemm.K = C; l.gemm.alpha = 1.0f / std::sqrt((float)C);
+            l.flops_per_sample = 2.0 * Lq * Lq * C;
+            c->tl.push_back(l);
+        }
+        { rdmi_ctx::TLaunch l; l.kind = 3; l.name = name + ".softmax"; l.oA = S.off; l.rows_per_sample = Lq; l.L = Lq; c->tl.push_back(l); }
+        { rdmi_ctx::TLaunch l; l.kind = 4; l.name = name + ".vT"; l.oA = qkv.off; l.oOut = Vt.off; l.tL = Lq; l.tC = C; l.tld = 3 * C; l.tc0 = 2 * C; c->tl.push_back(l); }
+        {
+            rdmi_ctx::TLaunch l; l.kind = 2; l.name = name + ".pv";
+            l.oA = S.off; l.oB = Vt.off; l.oC = O.off;
+            l.gemm.sa = (long)Lq * Lq; l.gemm.sb = (long)C * Lq; l.gemm.sc = (long)Lq * C; l.gemm.lda = Lq; l.gemm.ldb = Lq; l.gemm.ldc = C;
+            l.gemm.M = Lq; l.gemm.N = C; l.gemm.K = Lq; l.gemm.alpha = 1.f;
+            l.flops_per_sample = 2.0 * Lq * Lq * C;
+            c->tl.push_back(l);
+        }
+        return conv(name + ".NIN_3", O, nullptr, nullptr, "", false, 1, 1, false, pack1x1(name + ".NIN_3", C, C), C, name + ".NIN_3.b", (size_t)-1, -1, &x,
+                    (float)(1.0 / std::sqrt(2.0)), false);
+    }
+};
+
+int build_tiled_plan(rdmi_ctx* c, Builder& b, const Layout& L, std::map<std::string, int>& dense_off) {
+    const rdmi_arch& a = c->arch;
+    using TT = TiledBuilder::TT;
+    TiledBuilder t{c, b};
+    int H = c->H, W = c->W;
+    TT xin = t.talloc(a.channels, H, W);               // NHWC copy of the caller's NCHW input
+    xin.off = rdmi_ctx::TLaunch::XIN;                  // marker: resolved to t_xin
+    TT h = t.conv("input_conv", xin, nullptr, nullptr, "", false, 9, 1, false, t.pack3x3("input_conv", a.channels, a.nf), a.nf, "input_conv.bias", (size_t)-1, -1,
+                  nullptr, 1.f, false);
+    c->tl.back().in_is_x = true;
+    std::vector<TT> hs{h};
+    int d = 0;
+    for (int i = 0; i < a.n_levels; ++i) {
+        for (int j = 0; j < a.num_res_blocks; ++j, ++d) {
+            const BlockSpec& bs = L.down[(size_t)d];
+            h = t.resblock(bs.name, h, nullptr, bs.cout, dense_off[bs.name]);
+            if (bs.attn) h = t.attn("down_attn." + std::to_string(d), h);
+            hs.push_back(h);
+        }
+        hs.push_back(h);
+        if (i != a.n_levels - 1) {
+            const std::string nm = "downsample." + std::to_string(i) + ".Conv_0";
+            h = t.conv(nm, h, nullptr, nullptr, "", false, 9, 2, false, t.pack3x3(nm, h.C, h.C), h.C, nm + ".bias", (size_t)-1, -1, nullptr, 1.f, false);
+        }
+    }
+    h = t.resblock("mid_block1", h, nullptr, L.mid_ch, dense_off["mid_block1"]);
+    if (a.attn_levels >> (a.n_levels - 1) & 1) return fail("attention at the bottleneck resolution (mid_attn) is not built");
+    h = t.resblock("mid_block2", h, nullptr, L.mid_ch, dense_off["mid_block2"]);
+    int u = 0;
+    for (int k = 0; k < a.n_levels; ++k) {
+        for (int j = 0; j < a.num_res_blocks + 1; ++j, ++u) {
+            const BlockSpec& bs = L.up[(size_t)u];
+            TT sk = hs.back();
+            hs.pop_back();
+            if (sk.H != h.H || sk.W != h.W) return fail("tiled plan: skip grid %dx%d != %dx%d (the nearest-resize fix of odd grids is only built for the workgroup-resident plan)", sk.H, sk.W, h.H, h.W);
+            h = t.resblock(bs.name, h, &sk, bs.cout, dense_off[bs.name]);
+            if (bs.attn) h = t.attn("up_attn." + std::to_string(u), h);
+        }
+        if (k != a.n_levels - 1) {
+            const std::string nm = "upsample." + std::to_string(k) + ".Conv_0";
+            h = t.conv(nm, h, nullptr, nullptr, "", false, 9, 1, true, t.pack3x3(nm, h.C, h.C), h.C, nm + ".bias", (size_t)-1, -1, nullptr, 1.f, false);
+        }
+    }
+    if (h.H != c->H || h.W != c->W) return fail("network output grid %dx%d != input %dx%d", h.H, h.W, c->H, c->W);
+    TT st = t.stats("out_norm", h, nullptr);
+    t.conv("out_conv", h, nullptr, &st, "out_norm", true, 9, 1, false, t.pack3x3("out_conv", h.C, a.channels), a.channels, "out_conv.bias", (size_t)-1, -1, nullptr, 1.f, true);
+    c->t_ws_per_sample = t.top;
+    c->tiled = true;
+    return 0;
+}
+
+// resolve a per-sample workspace offset to a device pointer (tensors are [tensor][n][...]: the offset scales with max_batch)
+inline float* tl_ptr(rdmi_ctx* c, size_t off, long delta = 0) {
+    if (off == rdmi_ctx::TLaunch::NONE) return nullptr;
+    if (off == rdmi_ctx::TLaunch::XIN) return c->t_xin;
+    return c->t_ws + off * (size_t)c->max_batch + delta;
+}
+
+int finish_tiled_plan(rdmi_ctx* c) {
+    const size_t NBmax = (size_t)c->max_batch;
+    const size_t E = (size_t)c->H * c->W * c->arch.channels;
+    HIP_OK(hipMalloc((void**)&c->t_ws, c->t_ws_per_sample * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->t_xin, E * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&c->t_out, E * NBmax * sizeof(float)));
+    for (auto& l : c->tl) {
+        if (l.kind == 0) {
+            TConvArgs& a = l.conv;
+            a.srcA = tl_ptr(c, l.oA); a.srcB = tl_ptr(c, l.oB); a.stats = tl_ptr(c, l.oStats); a.resid = tl_ptr(c, l.oResid);
+            a.out = l.out_is_final ? c->t_out : tl_ptr(c, l.oOut);
+            a.wpk = c->d_w + l.w_off;
+            a.dense = l.use_dense ? c->d_dense : nullptr;
+            if (tconv_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_lds_bytes(a));
+        } else if (l.kind == 1) {
+            l.sA = tl_ptr(c, l.oA); l.sB = tl_ptr(c, l.oB); l.stats = tl_ptr(c, l.oStats);
+        } else if (l.kind == 2) {
+            l.gemm.A = tl_ptr(c, l.oA, l.dA); l.gemm.B = tl_ptr(c, l.oB, l.dB); l.gemm.C = tl_ptr(c, l.oC);
+        } else if (l.kind == 3) {
+            l.sm = tl_ptr(c, l.oA);
+        } else {
+            l.tsrc = tl_ptr(c, l.oA); l.tdst = tl_ptr(c, l.oOut);
+        }
+    }
+    return 0;
+}
+
+// replay the tiled plan for NB samples (embedding already evaluated into d_dense); x is NCHW, out is NCHW
+int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_mod, int sig_is_time, float t_scalar, float smin, float ratio, float* out, int NB,
+              const float* dense_rows, hipStream_t s);
 int build_fused_program(rdmi_ctx* c);
 
 int build_plan(rdmi_ctx* c) {
@@ -512,6 +737,29 @@ int build_plan(rdmi_ctx* c) {
         b.job_copy(d.first + ".Dense_0.bias", c->b_dense, d.second, dense_off[d.first]);
     }
 
+    // Shapes beyond one workgroup per sample (more than 96 pixels, or more than one image channel: the CIFAR-shape model of
+    // BASELINE config #5) run the spatially tiled plan; the GTO-Halo shapes keep the workgroup-resident / layer plans below.
+    if (c->H * c->W > 96 || a.channels != 1) {
+        try { if (int e = build_tiled_plan(c, b, L, dense_off)) return e; }
+        catch (const std::exception& ex) { return fail("tiled plan: %s", ex.what()); }
+        c->w_floats = b.wf;
+        HIP_OK(hipMalloc((void**)&c->d_w, c->w_floats * sizeof(float)));
+        HIP_OK(hipMemset(c->d_w, 0, c->w_floats * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_jobs, c->jobs.size() * sizeof(PackJob)));
+        const size_t NBm = (size_t)c->max_batch, Mp_ = (size_t)pad16(c->max_batch), E_ = (size_t)c->H * c->W * a.channels;
+        HIP_OK(hipMalloc((void**)&c->d_h1, Mp_ * T * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_temb, Mp_ * T * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_dense, Mp_ * dt * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_s2, NBm * E_ * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_score, NBm * E_ * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_z, NBm * E_ * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_norms, (2 * NBm + 2) * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_tvec, NBm * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&c->d_state, sizeof(StepState)));
+        HIP_OK(hipMemset(c->d_state, 0, sizeof(StepState)));
+        for (auto& j : c->jobs) j.dst = c->d_w + reinterpret_cast<size_t>(j.dst);
+        return finish_tiled_plan(c);
+    }
     // ---- NCSNpp.forward data flow
     int H = c->H, W = c->W;
     ConvSpec in;
@@ -577,7 +825,6 @@ int build_plan(rdmi_ctx* c) {
     out.gn = "out_norm"; out.conv = "out_conv"; out.Ho = H; out.Wo = W; out.Cout = a.channels; out.to_output = true;
     b.add_conv(out, &err);
     if (err) return err;
-    if (a.channels != 1) return fail("channels=%d: the NHWC->NCHW output boundary is only built for channels=1", a.channels);
 
     // ---- liveness-packed workspace offsets
     {
@@ -1341,6 +1588,12 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
             op.attn.gamma = P(c, op.p_gamma); op.attn.beta = P(c, op.p_beta); op.attn.b3 = P(c, op.p_b3);
         }
     }
+    for (auto& l : c->tl) {
+        if (l.kind != 0) continue;
+        l.conv.bias = l.p_bias.empty() ? c->d_w + l.bias_arena : P(c, l.p_bias);
+        l.conv.gamma = l.p_gamma.empty() ? nullptr : P(c, l.p_gamma);
+        l.conv.beta = l.p_beta.empty() ? nullptr : P(c, l.p_beta);
+    }
     for (auto& q : c->progs) {
         if (!q.ok) continue;
         for (auto& f : q.fpatch) {
@@ -1377,7 +1630,7 @@ struct FwdIn {
 int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     const rdmi_arch& a = c->arch;
     if (f.NB < 1 || f.NB > c->max_batch) return fail("batch %d outside [1, %d] (rdmi_create max_batch)", f.NB, c->max_batch);
-    if (a.scale_by_sigma) return fail("scale_by_sigma=True is not built (all shipped NCSN++ configs set it False, RD/configs/model/ncsnpp.yaml)");
+    if (a.scale_by_sigma && !c->tiled) return fail("scale_by_sigma=True is only built for the tiled plan (the shipped GTO-Halo config sets it False, RD/configs/model/ncsnpp.yaml)");
     if (a.conditional && !f.labels) return fail("class_labels is required: the model is conditional (label_emb) -- reference raises here too (RD/models/ncsnpp.py:262)");
     const int T = c->temb, Np_t = (T + 63) & ~63, Np_d = (c->dense_total + 63) & ~63;
     // ---- embedding: Fourier -> Linear -> SiLU -> Linear (+label_emb) -> [SiLU -> all Dense_0]
@@ -1415,6 +1668,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     }
     }
     HIP_OK(hipGetLastError());
+    if (c->tiled) return run_tiled(c, f.x, f.x_mod, f.sig, f.sig_mod, f.t_is_time, f.t_scalar, f.smin, f.ratio, f.out, f.NB, f.dense_rows, s);
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
     const rdmi_ctx::FusedProg* fq = (c->use_fused && !c->debug_taps) ? c->pick(f.NB) : nullptr;
     if (fq) {
@@ -1458,6 +1712,48 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     return 0;
 }
 
+
+int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_mod, int sig_is_time, float t_scalar, float smin, float ratio, float* out, int NB,
+              const float* dense_rows, hipStream_t s) {
+    const rdmi_arch& a = c->arch;
+    const int HW = c->H * c->W, Cc = a.channels;
+    const long tot = (long)NB * HW * Cc;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((tot + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, x, c->t_xin, NB, HW, Cc, x_mod);
+    for (auto& l : c->tl) {
+        if (l.kind == 0) {
+            TConvArgs ca = l.conv;
+            ca.NB = NB;
+            if (ca.dense && dense_rows) ca.dense = dense_rows;        // the sampler's per-update Dense_0 rows
+            if (l.out_is_final && a.scale_by_sigma) {               // h / time_cond (RD/models/ncsnpp.py:350-351)
+                if (sig) { ca.sig = sig; ca.sig_mod = sig_mod; ca.sig_is_time = sig_is_time; ca.smin = smin; ca.ratio = ratio; }
+                else ca.out_scale /= sig_is_time ? smin * powf(ratio, t_scalar) : t_scalar;
+            }
+            const unsigned tiles = (unsigned)ceil_div(ca.Ho, ca.TR);
+            dim3 grid(tiles * (unsigned)NB, (unsigned)ceil_div(ca.Cout_pad, 64));
+            ProfScope ps(c, s, l.nmt == 4 ? "tconv_kernel<4>" : "tconv_kernel<1>", l.flops_per_sample * NB);
+            if (l.nmt == 4) hipLaunchKernelGGL(tconv_kernel<4>, grid, dim3(RDMI_THREADS), tconv_lds_bytes(ca), s, ca);
+            else hipLaunchKernelGGL(tconv_kernel<1>, grid, dim3(RDMI_THREADS), tconv_lds_bytes(ca), s, ca);
+        } else if (l.kind == 1) {
+            ProfScope ps(c, s, "gn_stats_kernel", 0);
+            hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)l.G, (unsigned)NB), dim3(RDMI_THREADS), 16, s, l.sA, l.sB, l.CA, l.CB, l.HW, l.G, 1e-6f, l.stats);
+        } else if (l.kind == 2) {
+            ProfScope ps(c, s, "bgemm_nt_kernel", l.flops_per_sample * NB);
+            hipLaunchKernelGGL(bgemm_nt_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
+        } else if (l.kind == 3) {
+            const long rows = l.rows_per_sample * NB;
+            ProfScope ps(c, s, "softmax_rows_kernel", 0);
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(RDMI_THREADS), 0, s, l.sm, rows, l.L);
+        } else {
+            const long n = (long)NB * l.tL * l.tC;
+            ProfScope ps(c, s, "transpose_lc_kernel", 0);
+            hipLaunchKernelGGL(transpose_lc_kernel, dim3((unsigned)((n + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, l.tsrc, l.tdst, NB, l.tL, l.tC, l.tld, l.tc0);
+        }
+    }
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)c->t_out, out, NB, HW, Cc);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 #include "train_plan.h"
@@ -1490,7 +1786,9 @@ int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** des
 const char* rdmi_path_info(rdmi_ctx* c) {
     static thread_local std::string s;
     if (!c) return "";
-    if (c->fused_ready() && c->use_fused && !c->debug_taps) {
+    if (c->tiled) {
+        s = "tiled: " + std::to_string(c->tl.size()) + " launches over HBM-resident NHWC tensors (" + std::to_string(c->t_ws_per_sample * 4 / 1024) + " KiB of activations per sample)";
+    } else if (c->fused_ready() && c->use_fused && !c->debug_taps) {
         s = "fused: workgroup-resident U-Net, " + std::to_string(c->progs[0].fprog.size()) + " ops, " + std::to_string(c->progs[0].fused_lds) + " B LDS";
         for (size_t i = 1; i < c->progs.size(); ++i)
             s += c->progs[i].ok ? "; S=" + std::to_string(c->progs[i].S) + " samples/workgroup from batch " + std::to_string(c->s_min_wg * c->progs[i].S) + " (" + std::to_string(c->progs[i].fprog.size()) + " ops)"
@@ -1536,7 +1834,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         delete T;
     }
     for (auto& q : c->progs) for (void* p : {(void*)q.d_fprog, (void*)q.d_ftabs, (void*)q.d_spill}) if (p) hipFree(p);
-    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all};
+    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all, c->t_ws, c->t_xin, c->t_out};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete c;
@@ -2010,9 +2308,23 @@ int rdmi_opt_step(rdmi_opt* q, const rdmi_opt_hyper* hy, float* total_norm_out, 
 
 int rdmi_get_tap(rdmi_ctx* c, const char* name, float* dst, size_t dst_numel, int* C, int* H, int* W, void* stream) {
     if (!c || !name || !dst) return fail("null argument");
-    if (!c->debug_taps) return fail("taps need RDMI_DEBUG_TAPS=1 at rdmi_create (buffers are reused otherwise)");
     hipStream_t s = (hipStream_t)stream;
     const std::string nm(name);
+    if (c->tiled) {      // the tiled plan never reuses a tensor: the output of a block is its last conv (Conv_1 / NIN_3)
+        for (auto it = c->tl.rbegin(); it != c->tl.rend(); ++it) {
+            if (it->kind != 0 || !(it->name == nm || it->name == nm + ".Conv_1" || it->name == nm + ".NIN_3")) continue;
+            const TConvArgs& a = it->conv;
+            if (C) *C = a.Cout; if (H) *H = a.Ho; if (W) *W = a.Wo;
+            const size_t per = (size_t)a.Cout * a.Ho * a.Wo;
+            const int nb = (int)std::min<size_t>(dst_numel / per, (size_t)c->max_batch);
+            hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)ceil_div((int)(nb * per), RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)a.out, dst, nb,
+                               a.Ho * a.Wo, a.Cout);
+            HIP_OK(hipGetLastError());
+            return 0;
+        }
+        return fail("no activation named '%s' in the tiled plan", name);
+    }
+    if (!c->debug_taps) return fail("taps need RDMI_DEBUG_TAPS=1 at rdmi_create (buffers are reused otherwise)");
     if (nm == "temb") {
         if (C) *C = c->temb; if (H) *H = 1; if (W) *W = 1;
         HIP_OK(hipMemcpyAsync(dst, c->d_temb, std::min(dst_numel, (size_t)c->max_batch * c->temb) * sizeof(float), hipMemcpyDeviceToDevice, s));

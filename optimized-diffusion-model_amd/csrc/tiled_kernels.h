@@ -1,0 +1,246 @@
+// Spatially TILED plan for NCSN++ shapes whose samples do not fit one workgroup (BASELINE config #5: the CIFAR-shape model,
+// 32x32 / 16x16 / 8x8 / 4x4 with 128-256 channels, attention over L = 256 positions; RD/configs/model/ddpmpp.yaml,
+// RD/models/ncsnpp.py:226-354, RD/models/layerspp.py:67-96,171-214).  Activations live in HBM as NHWC fp32
+// [n][pixel][C]; every layer is a launch (the 9x9 GTO-Halo model keeps its workgroup-resident kernel).
+//
+//   tconv_kernel   3x3 / 1x1 convolution as an implicit GEMM on the exact-fp32 MFMA.  A workgroup owns a tile of whole output
+//                  image rows (64 output pixels) x 64 output channels.  Per 32-channel slab of the input it stages the tile's
+//                  VIRTUAL input window -- after concat, nearest x2 upsampling, zero padding, and GroupNorm + SiLU applied on
+//                  the fly from precomputed per-(sample, group) statistics -- in LDS ([pixel][32+4] fp32: conflict-free
+//                  ds_read_b128 A fragments); the 9 taps are row offsets into that window.  Weights use the same packed layout
+//                  as everywhere else ([tap][Cin/16][Cout_pad][16]: a wave's B fragment is 1 KiB contiguous).
+//                  Epilogue: bias, Dense_0(temb) column add, residual, 1/sqrt2, optional 1/sigma (scale_by_sigma).
+//   gn_stats_kernel  two-pass mean / rstd per (sample, group) over a (possibly concatenated) tensor.
+//   bgemm_nt_kernel  batched C = alpha * A B^T on the fp32 MFMA (attention scores Q K^T and P V with V transposed).
+//   softmax_rows_kernel, transpose_lc_kernel, nchw/nhwc copies: the rest of AttnBlockpp and the API boundary.
+#pragma once
+#include "common.h"
+
+struct TConvArgs {
+    const float* srcA; const float* srcB;   // virtual input channels = concat(A [n][Ha*Wa][CA], B [n][Ha*Wa][CB]); B may be null
+    int CA, CB, Cv;                         // Cv = CA + CB padded to a multiple of 32 (channels beyond CA + CB read as zero)
+    int Ha, Wa;                             // source grid
+    int up;                                 // 1: nearest x2 upsampling of the source (F.interpolate(scale_factor=2), layerspp.py:122)
+    int Hv, Wv;                             // virtual input grid (after upsampling)
+    int stride, pad_lo, ntap;               // 3x3: (1, 1, 9) or Downsample's (2, 0, 9) with the implicit bottom/right zero; 1x1: (1, 0, 1)
+    int Ho, Wo, TR;                         // output grid; output image rows per tile (TR * Wo = 64, or the whole 4x4 image)
+    const float* stats; int G, Cg;          // GroupNorm: [n][G][2] (mean, rstd) or null; Cg channels per group (multiple of 4)
+    const float* gamma; const float* beta; int act;
+    const float* wpk;                       // [ntap][Cv/16][Cout_pad][16]
+    const float* bias;
+    const float* dense; int dense_stride, dense_off;   // null or [n][dense_stride]: + dense[n][dense_off + col]
+    const float* resid;                     // null or [n][Ho*Wo][Cout]
+    float out_scale;
+    const float* sig; int sig_is_time, sig_mod; float smin, ratio;   // scale_by_sigma: out /= sigma[n % sig_mod] (null: off)
+    float* out; int Cout, Cout_pad;
+    int NB;
+};
+
+__host__ __device__ inline int tconv_trv(const TConvArgs& a) { return a.ntap == 1 ? a.TR : (a.TR - 1) * a.stride + 3; }
+__host__ __device__ inline int tconv_wl(const TConvArgs& a) { return a.ntap == 1 ? a.Wo : (a.Wo - 1) * a.stride + 3; }
+__host__ __device__ inline size_t tconv_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * 36 * 4; }
+
+// NMT row tiles of 16 output pixels per wave (4: a 64-pixel tile; 1: the whole 4x4 image)
+template <int NMT>
+__global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
+    float* L = reinterpret_cast<float*>(rdmi_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int tiles_per_img = (a.Ho + a.TR - 1) / a.TR;
+    const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
+    const int oy0 = tile * a.TR;
+    const int col = blockIdx.y * 64 + wave * 16 + lrow;
+    const int TRv = tconv_trv(a), Wl = tconv_wl(a), RS = 36;
+    const int npix = TRv * Wl;
+    const int vy0 = oy0 * a.stride - a.pad_lo, vx0 = -a.pad_lo;
+    const int Cin = a.CA + a.CB;
+    f32x4 acc[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LDS pixel of (row tile i, lane's output pixel) at tap (0, 0)
+    int pbase[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) {
+        const int m = min(i * 16 + lrow, a.TR * a.Wo - 1);
+        const int oyl = m / a.Wo, ox = m - oyl * a.Wo;
+        pbase[i] = (oyl * a.stride) * Wl + ox * a.stride;
+    }
+    const size_t bstride = (size_t)a.Cout_pad * 16;
+    const int nchunk16 = a.Cv >> 4;
+    const float* Wl_ = a.wpk + (size_t)min(col, a.Cout_pad - 1) * 16 + kq * 4;
+    for (int c0 = 0; c0 < a.Cv; c0 += 32) {
+        // ---- stage the virtual input window of channels [c0, c0 + 32): 8 float4 per pixel
+        for (int i = tid; i < npix * 8; i += RDMI_THREADS) {
+            const int p = i >> 3, q = i & 7;
+            const int ry = p / Wl, rx = p - ry * Wl;
+            const int vy = vy0 + ry, vx = vx0 + rx;
+            const int c = c0 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv && c < Cin) {
+                const int sy = a.up ? (vy >> 1) : vy, sx = a.up ? (vx >> 1) : vx;
+                const size_t sp = (size_t)n * a.Ha * a.Wa + (size_t)sy * a.Wa + sx;
+                if (c < a.CA) {
+                    const float* ptr = a.srcA + sp * a.CA + c;
+                    if ((a.CA & 3) == 0) v = *reinterpret_cast<const f32x4*>(ptr);
+                    else
+                        for (int j = 0; j < 4; ++j)
+                            if (c + j < a.CA) v[j] = ptr[j];
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(a.srcB + sp * a.CB + (c - a.CA));
+                }
+                if (a.stats) {
+                    const int g = c / a.Cg;
+                    const float mean = a.stats[((size_t)n * a.G + g) * 2], rstd = a.stats[((size_t)n * a.G + g) * 2 + 1];
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
+                    for (int j = 0; j < 4; ++j) {
+                        const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
+                        v[j] = a.act ? silu_f(y) : y;
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(L + (size_t)p * RS + q * 4) = v;
+        }
+        __syncthreads();
+        // ---- 9 taps x two 16-channel halves of the slab
+        if (col < a.Cout_pad) {
+            for (int t = 0; t < a.ntap; ++t) {
+                const int toff = a.ntap == 1 ? 0 : (t / 3) * Wl + (t % 3);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 bf = ldg4(Wl_ + ((size_t)t * nchunk16 + (c0 >> 4) + h) * bstride);
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) {
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(L + (size_t)(pbase[i] + toff) * RS + h * 16 + kq * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i] = mfma16(af[j], bf[j], acc[i]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue
+    if (col >= a.Cout) return;
+    float add = a.bias ? a.bias[col] : 0.f;
+    if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
+    float scale = a.out_scale;
+    if (a.sig) {
+        const float sv = a.sig[a.sig_mod > 0 ? n % a.sig_mod : n];
+        scale /= a.sig_is_time ? a.smin * powf(a.ratio, sv) : sv;
+    }
+    const int HWo = a.Ho * a.Wo, tile_px = a.TR * a.Wo;
+#pragma unroll
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = i * 16 + kq * 4 + r;
+            const int opix = oy0 * a.Wo + m;
+            if (m < tile_px && opix < HWo) {
+                const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
+                float v = acc[i][r] + add;
+                if (a.resid) v += a.resid[o];
+                a.out[o] = v * scale;
+            }
+        }
+}
+
+// mean / rstd of GroupNorm group g of sample n over concat(A, B): grid = (G, NB); two passes (exact like F.group_norm)
+__global__ __launch_bounds__(RDMI_THREADS) void gn_stats_kernel(const float* __restrict__ A, const float* __restrict__ B, int CA, int CB, int HW,
+                                                                 int G, float eps, float* __restrict__ stats) {
+    float* red = reinterpret_cast<float*>(rdmi_lds);      // [4]
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int C = CA + CB, Cg = C / G, c0 = g * Cg;
+    const int total = HW * Cg;
+    auto at = [&](int i) {
+        const int p = i / Cg, c = c0 + (i - p * Cg);
+        return c < CA ? A[((size_t)n * HW + p) * CA + c] : B[((size_t)n * HW + p) * CB + (c - CA)];
+    };
+    auto block_sum = [&](float v) {
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float s = 0.f;
+    for (int i = tid; i < total; i += RDMI_THREADS) s += at(i);
+    const float mean = block_sum(s) / (float)total;
+    float q = 0.f;
+    for (int i = tid; i < total; i += RDMI_THREADS) { const float d = at(i) - mean; q += d * d; }
+    const float var = block_sum(q) / (float)total;
+    if (tid == 0) { stats[((size_t)n * G + g) * 2] = mean; stats[((size_t)n * G + g) * 2 + 1] = 1.0f / sqrtf(var + eps); }
+}
+
+// C[n][m][j] = alpha * sum_k A[n][m][k] * B[n][j][k]  (both operands K-contiguous with row strides lda / ldb and batch strides
+// sa / sb).  Workgroup = 64 x 64 tile: wave w owns rows 16w..16w+15 and all four 16-column tiles.  M, N multiples of 16, K of 16.
+struct BgemmArgs { const float* A; const float* B; float* C; long sa, sb, sc; int lda, ldb, ldc; int M, N, K; float alpha; };
+__global__ __launch_bounds__(RDMI_THREADS) void bgemm_nt_kernel(BgemmArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.z;
+    const int row = blockIdx.x * 64 + wave * 16 + lrow;
+    const float* Ap = a.A + (size_t)n * a.sa + (size_t)min(row, a.M - 1) * a.lda + kq * 4;
+    const float* Bp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Bp[t] = a.B + (size_t)n * a.sb + (size_t)min((int)blockIdx.y * 64 + t * 16 + lrow, a.N - 1) * a.ldb + kq * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < a.K; k += 16) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(Ap + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(Bp[t] + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t] = mfma16(af[j], bf[j], acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = blockIdx.y * 64 + t * 16 + lrow;
+        if (c >= a.N) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int m = blockIdx.x * 64 + wave * 16 + kq * 4 + r;
+            if (m < a.M) a.C[(size_t)n * a.sc + (size_t)m * a.ldc + c] = acc[t][r] * a.alpha;
+        }
+    }
+}
+
+// in-place softmax over the last dimension of [rows][L]: one wave per row (F.softmax(w, dim=-1), layerspp.py:89)
+__global__ __launch_bounds__(RDMI_THREADS) void softmax_rows_kernel(float* __restrict__ x, long rows, int L) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = x + row * L;
+    float mx = -3.0e38f;
+    for (int i = lane; i < L; i += 64) mx = fmaxf(mx, p[i]);
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) { const float e = __expf(p[i] - mx); p[i] = e; s += e; }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < L; i += 64) p[i] *= inv;
+}
+
+// dst[n][c][l] = src[n][l][c0 + c] (row stride lds_): V -> V^T for the P V product
+__global__ __launch_bounds__(RDMI_THREADS) void transpose_lc_kernel(const float* __restrict__ src, float* __restrict__ dst, int NB, int L, int C, int ld, int c0) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)NB * L * C) return;
+    const int l = (int)(i % L);
+    const long r = i / L;
+    const int c = (int)(r % C);
+    const long n = r / C;
+    dst[i] = src[((size_t)n * L + l) * ld + c0 + c];
+}
+
+// API boundary for channels > 1: NCHW (the reference's layout) <-> NHWC
+__global__ __launch_bounds__(RDMI_THREADS) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int NB, int HW, int C, int x_mod) {
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)NB * HW * C) return;
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int p = (int)(r % HW);
+    const long n = r / HW;
+    const long ns = x_mod > 0 ? n % x_mod : n;
+    dst[i] = src[(ns * C + c) * HW + p];
+}

@@ -319,6 +319,52 @@ def gen_ode():
     save('ode_rk45.npz', **out)
 
 
+def make_cifar_cfg():
+    """BASELINE config #5: RD/configs/model/ddpmpp.yaml completed with the keys the fork's NCSNpp.__init__ requires and the yaml
+    lacks: channels=3, image_size=32, num_classes=1 with zero labels (conditional: True would otherwise call
+    label_emb(None))."""
+    cfg = make_cfg()
+    m = cfg.model
+    m.nf, m.ch_mult, m.num_res_blocks, m.attn_resolutions = 128, [1, 2, 2, 2], 8, [16]
+    m.channels, m.image_size, m.image_width, m.scale_by_sigma, m.dropout = 3, 32, 32, True, 0.1
+    cfg.sde.sigma_max = 50
+    return cfg
+
+
+CIFAR_ARCH = dict(nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=8, attn_resolutions=(16,), image_size=32, channels=3)
+
+
+def gen_cifar():
+    """Whole-forward golden of the CIFAR-shape NCSN++ (104.7 M parameters, 18.5 GMAC per sample): B=2, zero labels, plus a few
+    intermediate activations captured by forward hooks (first / last block of each level, one attention block)."""
+    cfg = make_cifar_cfg()
+    model = mutils.create_model(cfg)
+    params = W.make_params(0, **CIFAR_ARCH)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    assert list(sd.keys()) == list(model.state_dict().keys()), 'state-dict order/name mismatch (CIFAR arch)'
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    sde = sde_lib.RVESDE(0.01, 50, N=1000)
+    g = torch.Generator().manual_seed(61)
+    B = 2
+    x = torch.rand(B, 3, 32, 32, generator=g)
+    t = torch.tensor([0.35, 0.8])
+    labels = torch.zeros(B, 1)
+    taps = {}
+    names = {'down_blocks.0': model.down_blocks[0], 'down_blocks.8': model.down_blocks[8], 'down_attn.8': model.down_attn[8],
+             'down_blocks.31': model.down_blocks[31], 'mid_block2': model.mid_block2, 'up_blocks.0': model.up_blocks[0],
+             'up_blocks.35': model.up_blocks[35]}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: taps.__setitem__(k, out.detach().numpy().copy())) for k, m in names.items()]
+    with torch.no_grad():
+        score = mutils.get_score_fn(sde, model)(x, t, class_labels=labels)
+    for h in hooks:
+        h.remove()
+    # taps are large (2 x 128 x 32 x 32 ...): keep a strided subsample [:, ::8 channels, ::4, ::4]
+    save('forward_cifar.npz', x=x.numpy(), t=t.numpy(), labels=labels.numpy(), score=score.numpy(),
+         n_params=np.int64(sum(p.numel() for p in model.parameters())),
+         **{'tap.' + k: v[:, ::8, ::4, ::4].copy() for k, v in taps.items()})
+
+
 def gen_init():
     """Reference init under torch.manual_seed(0): lets the build's parameter shell prove it consumes the torch RNG
     identically (same construction order)."""
@@ -394,6 +440,9 @@ def gen_gto_dataset():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['cifar']:
+        gen_cifar()
+        sys.exit(0)
     if sys.argv[1:] == ['ode']:
         gen_ode()
         sys.exit(0)
@@ -412,4 +461,5 @@ if __name__ == '__main__':
     gen_train()
     gen_train_w0()
     gen_ode()
+    gen_cifar()
     gen_init()

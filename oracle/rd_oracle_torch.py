@@ -53,8 +53,8 @@ def _attn(p, pre, x):
     return (x + _nin(h, p, pre + '.NIN_3')) / math.sqrt(2.)
 
 
-def ncsnpp_forward(p, x, sigma, labels, ch_mult=(1, 2, 2), nrb=2, attn_levels=(True, False, False)):
-    """NCSNpp.forward, eval mode (RD/models/ncsnpp.py:226-354)."""
+def ncsnpp_forward(p, x, sigma, labels, ch_mult=(1, 2, 2), nrb=2, attn_levels=(True, False, False), scale_by_sigma=False):
+    """NCSNpp.forward, eval mode (RD/models/ncsnpp.py:226-354); scale_by_sigma: h / time_cond (:350-351)."""
     xp = (torch.log(sigma)[:, None] * p['time_embed.W'][None, :]) * 2 * math.pi
     temb = torch.cat([torch.sin(xp), torch.cos(xp)], dim=-1)
     temb = F.linear(F.silu(F.linear(temb, p['time_mlp.0.weight'], p['time_mlp.0.bias'])), p['time_mlp.2.weight'], p['time_mlp.2.bias'])
@@ -85,25 +85,29 @@ def ncsnpp_forward(p, x, sigma, labels, ch_mult=(1, 2, 2), nrb=2, attn_levels=(T
         if i != nlev - 1:
             h = F.interpolate(h, scale_factor=2, mode='nearest')
             h = F.conv2d(h, p[f'upsample.{i}.Conv_0.weight'], p[f'upsample.{i}.Conv_0.bias'], padding=1)
-    return F.conv2d(F.silu(_gn(h, p, 'out_norm')), p['out_conv.weight'], p['out_conv.bias'], padding=1)
+    h = F.conv2d(F.silu(_gn(h, p, 'out_norm')), p['out_conv.weight'], p['out_conv.bias'], padding=1)
+    return h / sigma.view(-1, 1, 1, 1) if scale_by_sigma else h
 
 
-def cf_score(p, x, t, labels, w):
+CIFAR_ARCH = dict(ch_mult=(1, 2, 2, 2), nrb=8, attn_levels=(False, True, False, False), scale_by_sigma=True)   # BASELINE config #5
+
+
+def cf_score(p, x, t, labels, w, smax=5.0, **arch):
     """RD/models/utils.py:120-138."""
     B = x.shape[0]
-    s = ncsnpp_forward(p, x.repeat(2, 1, 1, 1), sigma_of(t.repeat(2)), torch.cat([labels, torch.zeros_like(labels)]))
+    s = ncsnpp_forward(p, x.repeat(2, 1, 1, 1), sigma_of(t.repeat(2), smax=smax), torch.cat([labels, torch.zeros_like(labels)]), **arch)
     w = w.view(-1, 1, 1, 1)
     return (1 + w) * s[:B] - w * s[B:]
 
 
-def pc_update(p, x, t, labels, w, z_pred, N, z_corr=None, snr=0.01):
+def pc_update(p, x, t, labels, w, z_pred, N, z_corr=None, snr=0.01, smax=5.0, **arch):
     """One iteration of the PC loop (RD/sampling.py:330-332): optional Langevin step, then Euler-Maruyama."""
     if z_corr is not None:
-        s = cf_score(p, x, t, labels, w)
+        s = cf_score(p, x, t, labels, w, smax=smax, **arch)
         gn = s.reshape(s.shape[0], -1).norm(dim=-1).mean(); zn = z_corr.reshape(s.shape[0], -1).norm(dim=-1).mean()
         step = (snr * zn / gn) ** 2 * 2
         x = reflect(x + step * s + torch.sqrt(step * 2) * z_corr)
-    s = cf_score(p, x, t, labels, w)
-    g = g_of(t)[:, None, None, None]
+    s = cf_score(p, x, t, labels, w, smax=smax, **arch)
+    g = g_of(t, smax=smax)[:, None, None, None]
     x_mean = x + (g ** 2 * s) / N
     return reflect(x_mean + g * math.sqrt(1.0 / N) * z_pred)

@@ -1,0 +1,32 @@
+"""CIFAR-shape NCSN++ (BASELINE config #5) through the tiled plan: golden forward check, then a short sampler timing."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'optimized-diffusion-model_amd'))
+import numpy as np, torch
+import __graft_entry__ as ge
+from rdmi import sampling, sde_lib
+from rdmi.models import utils as mutils
+dev = torch.device('cuda:0')
+t0 = time.time()
+model, cfg, params = ge.make_cifar_model(dev)
+print('model built', time.time() - t0, flush=True)
+g = np.load(os.path.join(ROOT, 'tests', 'golden', 'forward_cifar.npz'))
+sde = sde_lib.RVESDE(0.01, 50, N=1000)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+with torch.no_grad():
+    s = mutils.get_score_fn(sde, model)(T(g['x']), T(g['t']), class_labels=T(g['labels']))
+torch.cuda.synchronize()
+print(model._ctx[(str(dev), 32, 32)].path_info())
+s = s.cpu().numpy()
+ref = g['score']
+for n in range(2):
+    print('sample', n, 'max |ref|', float(np.abs(ref[n]).max()), 'max err', float(np.abs(s[n] - ref[n]).max()), 'rel', float(np.abs(s[n] - ref[n]).max() / np.abs(ref[n]).max()))
+if len(sys.argv) > 1:
+    B, N = int(sys.argv[1]), int(sys.argv[2])
+    m2, cfg2, _ = ge.make_cifar_model(dev, num_scales=N)
+    sde2 = sde_lib.RVESDE(0.01, 50, N=N)
+    lab = torch.zeros(B, 1, device=dev)
+    fn = sampling.get_sampling_fn(cfg2, sde2, (B, 3, 32, 32), 1e-5, dev)
+    fn(m2, weight=0.0, class_labels=lab); torch.cuda.synchronize()
+    t0 = time.time(); x, nfe = fn(m2, weight=0.0, class_labels=lab); torch.cuda.synchronize(); dt = time.time() - t0
+    print(f'B={B} N={N}: {dt/(N-1)*1e3:.2f} ms/update -> {B/(dt/(N-1)*999):.3f} traj/s at 1000 scales; finite {bool(torch.isfinite(x).all())}')
