@@ -248,18 +248,20 @@ def variants(ge, dev, args, labels):
                      'plan': model._ctx[(str(dev), 9, 9)].path_info(),
                      'whole_path_frac_of_fp32_peak': (Bv / per_1000) * 2 * 999 * GFLOP_PER_FORWARD / 1e3 / PEAK_FP32_MFMA_TFLOPS}
         del model
-    out['cifar_b16'] = cifar_variant(ge, dev, 16)
+    out['cifar_b64'] = cifar_variant(ge, dev, 64)
+    out['cifar_b64_bf16'] = cifar_variant(ge, dev, 64, dtype='bf16')
     out['train_b128'] = train_variant(ge, dev, 128)
     return out
 
 
-def cifar_variant(ge, dev, B, N=9):
+def cifar_variant(ge, dev, B, N=5, dtype='f32'):
     """BASELINE config #5: the CIFAR-shape NCSN++ (32x32x3, nf=128, ch_mult [1,2,2,2], 8 res blocks, attention at 16x16, 104.7 M
     parameters, 36.9 GFLOP per sample-forward) through the tiled plan, fp32, guidance path on (2B forwards per update).  A
-    1000-scale trajectory of this model is ~25 s per batch: N-1 = 8 updates are timed and scaled per update."""
+    1000-scale trajectory of this model is ~1 min per batch of 64: N-1 = 4 updates are timed and scaled per update.  dtype 'bf16':
+    bf16 MFMA operands with fp32 accumulate (the BASELINE line asks bf16); `frac` is against the peak of the MFMA dtype used."""
     from rdmi import sampling, sde_lib
     GF = 36.912                                            # 18.456 GMAC per sample-forward (SURVEY 8d)
-    model, cfg, _ = ge.make_cifar_model(dev, num_scales=N)
+    model, cfg, _ = ge.make_cifar_model(dev, num_scales=N, compute_dtype=dtype)
     sde = sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=N)
     lab = torch.zeros(B, 1, device=dev)
     fn = sampling.get_sampling_fn(cfg, sde, (B, 3, 32, 32), 1e-5, dev)
@@ -270,7 +272,8 @@ def cifar_variant(ge, dev, B, N=9):
     assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
     tf = 2 * B * GF / dt / 1e3
     return {'value': B / (dt * 999), 'unit': 'trajectories/s (scaled to 1000 scales from %d timed updates)' % (N - 1), 'batch': B,
-            'ms_per_update': 1e3 * dt, 'dtype': 'f32', 'tflops': tf, 'frac': tf / PEAK_FP32_MFMA_TFLOPS,
+            'ms_per_update': 1e3 * dt, 'dtype': dtype, 'tflops': tf, 'frac': tf / (PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else 2500.0),
+            'peak_tflops': PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else 2500.0,
             'plan': model._ctx[(str(dev), 32, 32)].path_info()}
 
 

@@ -41,6 +41,8 @@ typedef struct rdmi_arch {
     int conditional;                /* config.model.conditional                         */
     int scale_by_sigma;             /* config.model.scale_by_sigma                      */
     float fourier_2pi_prescaled;    /* reserved, must be 0                              */
+    int compute_dtype;              /* 0: fp32 (the reference's arithmetic); 1: bf16 MFMA operands with fp32 accumulate, fp32
+                                       tensors and fp32 GroupNorm / softmax (tiled plan only: BASELINE config #5) */
 } rdmi_arch;
 
 typedef struct rdmi_ctx rdmi_ctx;

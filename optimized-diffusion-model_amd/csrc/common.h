@@ -34,6 +34,26 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// bf16 operands (BASELINE configs #4 / #5): storage is uint16 everywhere; v_mfma_f32_16x16x32_bf16 takes 8 bf16 per lane:
+// lane l supplies A[row l&15][k = 8(l>>4) + j] and B[k = 8(l>>4) + j][col l&15], j = 0..7; C/D layout as the fp32 form.
+typedef unsigned short bf16_t;
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 rdmi_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rdmi_bf16x8, a), __builtin_bit_cast(rdmi_bf16x8, b), c, 0, 0, 0);
+}
+#else
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4, u32x4, f32x4 c) { abort(); return c; }      // the CPU emulator does not execute bf16 kernels
+#endif
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
 // All-reduce over the 16 lanes of a DPP row (lanes 16r..16r+15) in four VALU-DPP steps (quad_perm xor 1, xor 2,
 // row_half_mirror, row_mirror).  __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round trip of ~100+ cycles per
 // step, four to six dependent steps per reduction); these stay in the VALU.  Each step adds the same two partial sums

@@ -17,7 +17,7 @@ struct PackJob {
     int n_off;                // first destination column of this job
     int ntap;
     long s_co, s_ci, s_t;     // source strides (elements) of output channel, input channel, tap
-    int kind;                 // 0: pack weights, 1: plain copy of Cout floats to dst + n_off
+    int kind;                 // 0: pack weights, 1: plain copy of Cout floats to dst + n_off, 2: pack weights as bf16 [tap][K/32][Npad][32]
 };
 
 __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __restrict__ jobs) {
@@ -25,6 +25,23 @@ __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __res
     const int stride = gridDim.x * RDMI_THREADS;
     if (j.kind == 1) {
         for (int i = blockIdx.x * RDMI_THREADS + threadIdx.x; i < j.Cout; i += stride) j.dst[j.n_off + i] = j.src[i];
+        return;
+    }
+    if (j.kind == 2) {        // bf16 copy of the weights for v_mfma_f32_16x16x32_bf16: 32 consecutive k per (k-slab, column)
+        const int ncol = (j.Cout + 15) & ~15;
+        bf16_t* d16 = reinterpret_cast<bf16_t*>(j.dst);
+        const long total = (long)j.ntap * (j.Kpad >> 5) * ncol * 32;
+        for (long i = blockIdx.x * RDMI_THREADS + threadIdx.x; i < total; i += stride) {
+            const int kk = (int)(i & 31);
+            long r = i >> 5;
+            const int co = (int)(r % ncol); r /= ncol;
+            const int ch = (int)(r % (j.Kpad >> 5));
+            const int t = (int)(r / (j.Kpad >> 5));
+            const int ci = ch * 32 + kk;
+            float v = 0.f;
+            if (co < j.Cout && ci < j.Cin) v = j.src[co * j.s_co + ci * j.s_ci + t * j.s_t];
+            d16[(((long)t * (j.Kpad >> 5) + ch) * j.Npad + j.n_off + co) * 32 + kk] = f2bf(v);
+        }
         return;
     }
     // destination element (t, ch, co_local, kk): each job owns the columns [n_off, n_off + ceil16(Cout))

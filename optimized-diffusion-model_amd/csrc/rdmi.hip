@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -513,16 +514,20 @@ struct TiledBuilder {
     TT talloc(int C, int H, int W) { TT t; t.off = top; t.C = C; t.H = H; t.W = W; t.valid = true; top += ((size_t)C * H * W + 63) & ~(size_t)63; return t; }
     static int pad32(int a) { return (a + 31) & ~31; }
 
+    bool bf16() const { return c->arch.compute_dtype == 1; }
+    // weights: fp32 [tap][K/16][Np][16], or the bf16 copy [tap][K/32][Np][32] (half the arena floats)
     size_t pack3x3(const std::string& pre, int cin, int cout) {
         const int Kp = pad32(cin), Np = pad16(cout);
-        const size_t o = b.alloc_w((size_t)9 * Kp * Np);
+        const size_t o = b.alloc_w(bf16() ? ((size_t)9 * Kp * Np + 1) / 2 : (size_t)9 * Kp * Np);
         b.job_pack(pre + ".weight", o, cin, cout, Kp, Np, 0, 9, (long)cin * 9, 9, 1);
+        if (bf16()) c->jobs.back().kind = 2;
         return o;
     }
     size_t pack1x1(const std::string& pre, int cin, int cout) {
         const int Kp = pad32(cin), Np = pad16(cout);
-        const size_t o = b.alloc_w((size_t)Kp * Np);
+        const size_t o = b.alloc_w(bf16() ? ((size_t)Kp * Np + 1) / 2 : (size_t)Kp * Np);
         b.job_pack(pre + ".W", o, cin, cout, Kp, Np, 0, 1, 1, cout, 0);
+        if (bf16()) c->jobs.back().kind = 2;
         return o;
     }
     TT stats(const std::string& name, const TT& A, const TT* B) {
@@ -580,11 +585,11 @@ struct TiledBuilder {
         const int C = x.C, Lq = x.H * x.W;
         if (C % 32 != 0 || Lq % 16 != 0) throw std::runtime_error("tiled attention needs C % 32 == 0 and H*W % 16 == 0");
         TT st = stats(name + ".GroupNorm_0", x, nullptr);
-        const size_t o3 = b.alloc_w((size_t)3 * C * C);
+        const size_t o3 = b.alloc_w(bf16() ? (size_t)3 * C * C / 2 : (size_t)3 * C * C);
         for (int i = 0; i < 3; ++i) {
             PackJob j{};
             j.dst = reinterpret_cast<float*>(o3);
-            j.Cin = C; j.Cout = C; j.Kpad = C; j.Npad = 3 * C; j.n_off = i * C; j.ntap = 1; j.s_co = 1; j.s_ci = C; j.s_t = 0; j.kind = 0;
+            j.Cin = C; j.Cout = C; j.Kpad = C; j.Npad = 3 * C; j.n_off = i * C; j.ntap = 1; j.s_co = 1; j.s_ci = C; j.s_t = 0; j.kind = bf16() ? 2 : 0;
             c->jobs.push_back(j);
             c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
         }
@@ -739,6 +744,8 @@ int build_plan(rdmi_ctx* c) {
 
     // Shapes beyond one workgroup per sample (more than 96 pixels, or more than one image channel: the CIFAR-shape model of
     // BASELINE config #5) run the spatially tiled plan; the GTO-Halo shapes keep the workgroup-resident / layer plans below.
+    if (a.compute_dtype != 0 && a.compute_dtype != 1) return fail("compute_dtype=%d (0: fp32, 1: bf16)", a.compute_dtype);
+    if (a.compute_dtype == 1 && !(c->H * c->W > 96 || a.channels != 1)) return fail("compute_dtype=bf16 is built for the tiled plan only (samples of more than 96 pixels or several channels)");
     if (c->H * c->W > 96 || a.channels != 1) {
         try { if (int e = build_tiled_plan(c, b, L, dense_off)) return e; }
         catch (const std::exception& ex) { return fail("tiled plan: %s", ex.what()); }
@@ -1729,16 +1736,30 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
                 else ca.out_scale /= sig_is_time ? smin * powf(ratio, t_scalar) : t_scalar;
             }
             const unsigned tiles = (unsigned)ceil_div(ca.Ho, ca.TR);
-            dim3 grid(tiles * (unsigned)NB, (unsigned)ceil_div(ca.Cout_pad, 64));
-            ProfScope ps(c, s, l.nmt == 4 ? "tconv_kernel<4>" : "tconv_kernel<1>", l.flops_per_sample * NB);
-            if (l.nmt == 4) hipLaunchKernelGGL(tconv_kernel<4>, grid, dim3(RDMI_THREADS), tconv_lds_bytes(ca), s, ca);
-            else hipLaunchKernelGGL(tconv_kernel<1>, grid, dim3(RDMI_THREADS), tconv_lds_bytes(ca), s, ca);
+            // column tiles per wave (the workgroup covers 64 * nct channels: staging and its GroupNorm/SiLU arithmetic are shared), as
+            // long as the launch still has >= 2 workgroups per CU
+            int nct = 1;
+            for (int cand : {4, 2})
+                if (ca.Cout_pad >= 64 * cand && (long)tiles * NB * ceil_div(ca.Cout_pad, 64 * cand) >= 512) { nct = cand; break; }
+            dim3 grid(tiles * (unsigned)NB, (unsigned)ceil_div(ca.Cout_pad, 64 * nct));
+            const bool h = a.compute_dtype == 1;
+            const size_t lds = h ? tconv_bf16_lds_bytes(ca) : tconv_lds_bytes(ca);
+            ProfScope ps(c, s, h ? "tconv_kernel<bf16>" : "tconv_kernel<fp32>", l.flops_per_sample * NB);
+#define RDMI_TCONV(NMT_, NCT_)                                                                                                        \
+    do {                                                                                                                              \
+        if (h) hipLaunchKernelGGL((tconv_kernel<NMT_, NCT_, true>), grid, dim3(RDMI_THREADS), lds, s, ca);                            \
+        else hipLaunchKernelGGL((tconv_kernel<NMT_, NCT_, false>), grid, dim3(RDMI_THREADS), lds, s, ca);                             \
+    } while (0)
+            if (l.nmt == 4) { if (nct == 4) RDMI_TCONV(4, 4); else if (nct == 2) RDMI_TCONV(4, 2); else RDMI_TCONV(4, 1); }
+            else { if (nct == 4) RDMI_TCONV(1, 4); else if (nct == 2) RDMI_TCONV(1, 2); else RDMI_TCONV(1, 1); }
+#undef RDMI_TCONV
         } else if (l.kind == 1) {
             ProfScope ps(c, s, "gn_stats_kernel", 0);
             hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)l.G, (unsigned)NB), dim3(RDMI_THREADS), 16, s, l.sA, l.sB, l.CA, l.CB, l.HW, l.G, 1e-6f, l.stats);
         } else if (l.kind == 2) {
-            ProfScope ps(c, s, "bgemm_nt_kernel", l.flops_per_sample * NB);
-            hipLaunchKernelGGL(bgemm_nt_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
+            ProfScope ps(c, s, a.compute_dtype == 1 ? "bgemm_nt_bf16_kernel" : "bgemm_nt_kernel", l.flops_per_sample * NB);
+            if (a.compute_dtype == 1) hipLaunchKernelGGL(bgemm_nt_bf16_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
+            else hipLaunchKernelGGL(bgemm_nt_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
         } else if (l.kind == 3) {
             const long rows = l.rows_per_sample * NB;
             ProfScope ps(c, s, "softmax_rows_kernel", 0);
@@ -1787,7 +1808,7 @@ const char* rdmi_path_info(rdmi_ctx* c) {
     static thread_local std::string s;
     if (!c) return "";
     if (c->tiled) {
-        s = "tiled: " + std::to_string(c->tl.size()) + " launches over HBM-resident NHWC tensors (" + std::to_string(c->t_ws_per_sample * 4 / 1024) + " KiB of activations per sample)";
+        s = std::string("tiled (") + (c->arch.compute_dtype == 1 ? "bf16 MFMA operands, fp32 accumulate" : "fp32") + "): " + std::to_string(c->tl.size()) + " launches over HBM-resident NHWC tensors (" + std::to_string(c->t_ws_per_sample * 4 / 1024) + " KiB of activations per sample)";
     } else if (c->fused_ready() && c->use_fused && !c->debug_taps) {
         s = "fused: workgroup-resident U-Net, " + std::to_string(c->progs[0].fprog.size()) + " ops, " + std::to_string(c->progs[0].fused_lds) + " B LDS";
         for (size_t i = 1; i < c->progs.size(); ++i)

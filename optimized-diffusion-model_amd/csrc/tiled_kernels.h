@@ -3,8 +3,8 @@
 // RD/models/ncsnpp.py:226-354, RD/models/layerspp.py:67-96,171-214).  Activations live in HBM as NHWC fp32
 // [n][pixel][C]; every layer is a launch (the 9x9 GTO-Halo model keeps its workgroup-resident kernel).
 //
-//   tconv_kernel   3x3 / 1x1 convolution as an implicit GEMM on the exact-fp32 MFMA.  A workgroup owns a tile of whole output
-//                  image rows (64 output pixels) x 64 output channels.  Per 32-channel slab of the input it stages the tile's
+//   tconv_kernel   3x3 / 1x1 convolution as an implicit GEMM on the exact-fp32 MFMA (or bf16 operands).  A workgroup owns a tile of
+//                  whole output image rows (64 output pixels) x 64..256 output channels.  Per 32-channel slab of the input it stages the tile's
 //                  VIRTUAL input window -- after concat, nearest x2 upsampling, zero padding, and GroupNorm + SiLU applied on
 //                  the fly from precomputed per-(sample, group) statistics -- in LDS ([pixel][32+4] fp32: conflict-free
 //                  ds_read_b128 A fragments); the 9 taps are row offsets into that window.  Weights use the same packed layout
@@ -40,23 +40,71 @@ __host__ __device__ inline int tconv_trv(const TConvArgs& a) { return a.ntap == 
 __host__ __device__ inline int tconv_wl(const TConvArgs& a) { return a.ntap == 1 ? a.Wo : (a.Wo - 1) * a.stride + 3; }
 __host__ __device__ inline size_t tconv_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * 36 * 4; }
 
-// NMT row tiles of 16 output pixels per wave (4: a 64-pixel tile; 1: the whole 4x4 image)
-template <int NMT>
+// NMT row tiles of 16 output pixels per wave (4: a 64-pixel tile; 1: the whole 4x4 image) x NCT adjacent 16-column tiles per wave:
+// a workgroup covers 64 * NCT output channels, so the staged window (and its GroupNorm + SiLU arithmetic) is shared by up to 256
+// output channels and every A fragment read from LDS feeds NCT MFMAs.
+// BF16 (BASELINE config #5 asks bf16 + MFMA): same tiling and staging, but the activated window is kept in LDS as bf16
+// ([pixel][32 + 8] bf16: one ds_read_b128 is a lane's whole A fragment of v_mfma_f32_16x16x32_bf16) and the weights come from the
+// bf16 copy packed [tap][Cin/32][Cout_pad][32]; accumulation, GroupNorm arithmetic, epilogue and the tensors in HBM stay fp32.
+// One MFMA per (tap, row tile, column tile, 32-channel slab) replaces eight fp32 ones at 1/16 of their cycles.
+__host__ __device__ inline size_t tconv_bf16_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * 40 * 2; }
+
+template <bool BF16>
+__device__ __forceinline__ void tconv_stage(const TConvArgs& a, int n, int c0, int vy0, int vx0, int Wl, int npix, int tid) {
+    const int Cin = a.CA + a.CB;
+    for (int i = tid; i < npix * 8; i += RDMI_THREADS) {
+        const int p = i >> 3, q = i & 7;
+        const int ry = p / Wl, rx = p - ry * Wl;
+        const int vy = vy0 + ry, vx = vx0 + rx;
+        const int c = c0 + q * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv && c < Cin) {
+            const int sy = a.up ? (vy >> 1) : vy, sx = a.up ? (vx >> 1) : vx;
+            const size_t sp = (size_t)n * a.Ha * a.Wa + (size_t)sy * a.Wa + sx;
+            if (c < a.CA) {
+                const float* ptr = a.srcA + sp * a.CA + c;
+                if ((a.CA & 3) == 0) v = *reinterpret_cast<const f32x4*>(ptr);
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < a.CA) v[j] = ptr[j];
+            } else {
+                v = *reinterpret_cast<const f32x4*>(a.srcB + sp * a.CB + (c - a.CA));
+            }
+            if (a.stats) {
+                const int g = c / a.Cg;
+                const float mean = a.stats[((size_t)n * a.G + g) * 2], rstd = a.stats[((size_t)n * a.G + g) * 2 + 1];
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
+                for (int j = 0; j < 4; ++j) {
+                    const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
+                    v[j] = a.act ? silu_f(y) : y;
+                }
+            }
+        }
+        if (BF16) {
+            typedef unsigned int u32x2 __attribute__((vector_size(8)));
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(rdmi_lds) + (size_t)p * 40 + q * 4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(rdmi_lds) + (size_t)p * 36 + q * 4) = v;
+        }
+    }
+}
+
+template <int NMT, int NCT, bool BF16>
 __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
-    float* L = reinterpret_cast<float*>(rdmi_lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kq = lane >> 4;
     const int tiles_per_img = (a.Ho + a.TR - 1) / a.TR;
     const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
     const int oy0 = tile * a.TR;
-    const int col = blockIdx.y * 64 + wave * 16 + lrow;
-    const int TRv = tconv_trv(a), Wl = tconv_wl(a), RS = 36;
+    const int col0 = blockIdx.y * (64 * NCT) + wave * (16 * NCT) + lrow;       // column of this lane in its first column tile
+    const int TRv = tconv_trv(a), Wl = tconv_wl(a);
     const int npix = TRv * Wl;
     const int vy0 = oy0 * a.stride - a.pad_lo, vx0 = -a.pad_lo;
-    const int Cin = a.CA + a.CB;
-    f32x4 acc[NMT];
+    f32x4 acc[NMT][NCT];
 #pragma unroll
-    for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
     // LDS pixel of (row tile i, lane's output pixel) at tap (0, 0)
     int pbase[NMT];
 #pragma unroll
@@ -65,54 +113,44 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
         const int oyl = m / a.Wo, ox = m - oyl * a.Wo;
         pbase[i] = (oyl * a.stride) * Wl + ox * a.stride;
     }
-    const size_t bstride = (size_t)a.Cout_pad * 16;
-    const int nchunk16 = a.Cv >> 4;
-    const float* Wl_ = a.wpk + (size_t)min(col, a.Cout_pad - 1) * 16 + kq * 4;
+    // weight fragment pointers of the NCT column tiles (columns beyond the padded width re-read the last one; never stored)
+    const float* Wf[NCT]; const bf16_t* Wh[NCT];
+#pragma unroll
+    for (int cc = 0; cc < NCT; ++cc) {
+        const int cl = min(col0 + cc * 16, a.Cout_pad - 16 + lrow);
+        Wf[cc] = a.wpk + (size_t)cl * 16 + kq * 4;
+        Wh[cc] = reinterpret_cast<const bf16_t*>(a.wpk) + (size_t)cl * 32 + kq * 8;
+    }
+    const size_t bstride = (size_t)a.Cout_pad * (BF16 ? 32 : 16);
+    const int nk = BF16 ? (a.Cv >> 5) : (a.Cv >> 4);                  // weight k-slabs per tap
     for (int c0 = 0; c0 < a.Cv; c0 += 32) {
-        // ---- stage the virtual input window of channels [c0, c0 + 32): 8 float4 per pixel
-        for (int i = tid; i < npix * 8; i += RDMI_THREADS) {
-            const int p = i >> 3, q = i & 7;
-            const int ry = p / Wl, rx = p - ry * Wl;
-            const int vy = vy0 + ry, vx = vx0 + rx;
-            const int c = c0 + q * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv && c < Cin) {
-                const int sy = a.up ? (vy >> 1) : vy, sx = a.up ? (vx >> 1) : vx;
-                const size_t sp = (size_t)n * a.Ha * a.Wa + (size_t)sy * a.Wa + sx;
-                if (c < a.CA) {
-                    const float* ptr = a.srcA + sp * a.CA + c;
-                    if ((a.CA & 3) == 0) v = *reinterpret_cast<const f32x4*>(ptr);
-                    else
-                        for (int j = 0; j < 4; ++j)
-                            if (c + j < a.CA) v[j] = ptr[j];
-                } else {
-                    v = *reinterpret_cast<const f32x4*>(a.srcB + sp * a.CB + (c - a.CA));
-                }
-                if (a.stats) {
-                    const int g = c / a.Cg;
-                    const float mean = a.stats[((size_t)n * a.G + g) * 2], rstd = a.stats[((size_t)n * a.G + g) * 2 + 1];
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
-                    for (int j = 0; j < 4; ++j) {
-                        const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
-                        v[j] = a.act ? silu_f(y) : y;
-                    }
-                }
-            }
-            *reinterpret_cast<f32x4*>(L + (size_t)p * RS + q * 4) = v;
-        }
+        tconv_stage<BF16>(a, n, c0, vy0, vx0, Wl, npix, tid);
         __syncthreads();
-        // ---- 9 taps x two 16-channel halves of the slab
-        if (col < a.Cout_pad) {
-            for (int t = 0; t < a.ntap; ++t) {
-                const int toff = a.ntap == 1 ? 0 : (t / 3) * Wl + (t % 3);
+        for (int t = 0; t < a.ntap; ++t) {
+            const int toff = a.ntap == 1 ? 0 : (t / 3) * Wl + (t % 3);
+            if (BF16) {
+                u32x4 bf[NCT];
+#pragma unroll
+                for (int cc = 0; cc < NCT; ++cc) bf[cc] = *reinterpret_cast<const u32x4*>(Wh[cc] + ((size_t)t * nk + (c0 >> 5)) * bstride);
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) {
+                    const u32x4 af = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(rdmi_lds) + (size_t)(pbase[i] + toff) * 40 + kq * 8);
+#pragma unroll
+                    for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = mfma16_bf16(af, bf[cc], acc[i][cc]);
+                }
+            } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const f32x4 bf = ldg4(Wl_ + ((size_t)t * nchunk16 + (c0 >> 4) + h) * bstride);
+                    f32x4 bf[NCT];
+#pragma unroll
+                    for (int cc = 0; cc < NCT; ++cc) bf[cc] = ldg4(Wf[cc] + ((size_t)t * nk + (c0 >> 4) + h) * bstride);
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) {
-                        const f32x4 af = *reinterpret_cast<const f32x4*>(L + (size_t)(pbase[i] + toff) * RS + h * 16 + kq * 4);
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rdmi_lds) + (size_t)(pbase[i] + toff) * 36 + h * 16 + kq * 4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i] = mfma16(af[j], bf[j], acc[i]);
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = mfma16(af[j], bf[cc][j], acc[i][cc]);
                     }
                 }
             }
@@ -120,28 +158,33 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
         __syncthreads();
     }
     // ---- epilogue
-    if (col >= a.Cout) return;
-    float add = a.bias ? a.bias[col] : 0.f;
-    if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
-    float scale = a.out_scale;
+    float sdiv = 1.f;
     if (a.sig) {
         const float sv = a.sig[a.sig_mod > 0 ? n % a.sig_mod : n];
-        scale /= a.sig_is_time ? a.smin * powf(a.ratio, sv) : sv;
+        sdiv = a.sig_is_time ? a.smin * powf(a.ratio, sv) : sv;
     }
+    const float scale = a.out_scale / sdiv;
     const int HWo = a.Ho * a.Wo, tile_px = a.TR * a.Wo;
 #pragma unroll
-    for (int i = 0; i < NMT; ++i)
+    for (int cc = 0; cc < NCT; ++cc) {
+        const int col = col0 + cc * 16;
+        if (col >= a.Cout) continue;
+        float add = a.bias ? a.bias[col] : 0.f;
+        if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = i * 16 + kq * 4 + r;
-            const int opix = oy0 * a.Wo + m;
-            if (m < tile_px && opix < HWo) {
-                const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
-                float v = acc[i][r] + add;
-                if (a.resid) v += a.resid[o];
-                a.out[o] = v * scale;
+        for (int i = 0; i < NMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i * 16 + kq * 4 + r;
+                const int opix = oy0 * a.Wo + m;
+                if (m < tile_px && opix < HWo) {
+                    const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
+                    float v = acc[i][cc][r] + add;
+                    if (a.resid) v += a.resid[o];
+                    a.out[o] = v * scale;
+                }
             }
-        }
+    }
 }
 
 // mean / rstd of GroupNorm group g of sample n over concat(A, B): grid = (G, NB); two passes (exact like F.group_norm)
@@ -194,6 +237,39 @@ __global__ __launch_bounds__(RDMI_THREADS) void bgemm_nt_kernel(BgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t] = mfma16(af[j], bf[j], acc[t]);
         }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = blockIdx.y * 64 + t * 16 + lrow;
+        if (c >= a.N) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int m = blockIdx.x * 64 + wave * 16 + kq * 4 + r;
+            if (m < a.M) a.C[(size_t)n * a.sc + (size_t)m * a.ldc + c] = acc[t][r] * a.alpha;
+        }
+    }
+}
+
+// bf16 variant: the fp32 operands are rounded to bf16 as they are loaded (8 consecutive k per lane), fp32 accumulate.  K % 32 == 0.
+__global__ __launch_bounds__(RDMI_THREADS) void bgemm_nt_bf16_kernel(BgemmArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.z;
+    const int row = blockIdx.x * 64 + wave * 16 + lrow;
+    const float* Ap = a.A + (size_t)n * a.sa + (size_t)min(row, a.M - 1) * a.lda + kq * 8;
+    const float* Bp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Bp[t] = a.B + (size_t)n * a.sb + (size_t)min((int)blockIdx.y * 64 + t * 16 + lrow, a.N - 1) * a.ldb + kq * 8;
+    auto frag = [](const float* p) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p), y = *reinterpret_cast<const f32x4*>(p + 4);
+        return u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < a.K; k += 32) {
+        const u32x4 af = frag(Ap + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16_bf16(af, frag(Bp[t] + k), acc[t]);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {

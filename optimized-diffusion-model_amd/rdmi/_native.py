@@ -23,7 +23,7 @@ class Arch(C.Structure):
     _fields_ = [('nf', C.c_int), ('n_levels', C.c_int), ('ch_mult', C.c_int * RDMI_MAX_LEVELS),
                 ('num_res_blocks', C.c_int), ('attn_levels', C.c_int), ('channels', C.c_int),
                 ('num_classes', C.c_int), ('conditional', C.c_int), ('scale_by_sigma', C.c_int),
-                ('fourier_2pi_prescaled', C.c_float)]
+                ('fourier_2pi_prescaled', C.c_float), ('compute_dtype', C.c_int)]
 
 
 class PcOpts(C.Structure):

@@ -116,6 +116,10 @@ class NCSNpp(nn.Module):
         self.image_width = getattr(m, 'image_width', m.image_size)
         self.channels = m.channels
         self.scale_by_sigma = getattr(m, 'scale_by_sigma', False)
+        # not a reference key: 'f32' (default, the reference's arithmetic) or 'bf16' (bf16 MFMA operands, fp32 accumulate; tiled plan)
+        self.compute_dtype = str(getattr(m, 'compute_dtype', 'f32'))
+        if self.compute_dtype not in ('f32', 'bf16'):
+            raise NotImplementedError(f'compute_dtype {self.compute_dtype!r}: f32 or bf16')
         # what the HIP plan implements; anything else fails here, loudly, not in a fallback
         if m.embedding_type != 'fourier':
             raise NotImplementedError('Only fourier embedding supported')          # as RD/models/ncsnpp.py:100
@@ -174,6 +178,7 @@ class NCSNpp(nn.Module):
         a.attn_levels = sum(1 << i for i, on in enumerate(self.attn_levels) if on)
         a.channels, a.num_classes = self.channels, self.num_classes
         a.conditional, a.scale_by_sigma = int(bool(self.conditional)), int(bool(self.scale_by_sigma))
+        a.compute_dtype = 1 if self.compute_dtype == 'bf16' else 0
         return a
 
     def native_context(self, model_batch, H, W, device):

@@ -105,3 +105,41 @@ def test_cifar_cfg_score_and_pc_update_vs_oracle(env):
         err = float((trace[i].reshape(B, 3, 32, 32) - r).abs().max())
         assert err <= 2e-5 + 1e-4 * gg * sc, (i, err, gg, sc)
     assert float(xs.min()) >= 0 and float(xs.max()) <= 1
+
+
+def test_cifar_bf16_forward_within_bf16_tolerance(env, golden):
+    """compute_dtype='bf16' (BASELINE config #5 as written: bf16 MFMA operands, fp32 accumulate / GroupNorm / softmax / tensors)
+    against the same reference-recorded forward.  Stated tolerance: 3e-2 of each sample's largest |score| at the maximum and 6e-3
+    in the root-mean-square (bf16 keeps 8 significant bits: 2^-9 relative rounding per operand through ~75 convolutions and 17
+    attention blocks; measured 1.4e-2 / 2.5e-3), and within that the fp32 plan (compute_dtype='f32') stays the parity reference:
+    its own tolerance is unchanged (test above)."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    g = golden('forward_cifar.npz')
+    dev, ge = env['dev'], env['ge']
+    model, cfg, _ = ge.make_cifar_model(dev, compute_dtype='bf16')
+    sde = sde_lib.RVESDE(0.01, 50, N=1000)
+    with torch.no_grad():
+        s = mutils.get_score_fn(sde, model)(T(g['x'], dev), T(g['t'], dev), class_labels=T(g['labels'], dev)).cpu().numpy()
+    assert 'bf16' in model._ctx[(str(dev), 32, 32)].path_info()
+    ref = g['score']
+    for n in range(2):
+        d = s[n] - ref[n]
+        assert np.abs(d).max() <= 3e-2 * np.abs(ref[n]).max(), (n, np.abs(d).max() / np.abs(ref[n]).max())
+        assert np.sqrt((d ** 2).mean()) <= 6e-3 * np.abs(ref[n]).max(), (n, np.sqrt((d ** 2).mean()) / np.abs(ref[n]).max())
+    # not a silent fp32 run: the result differs from the fp32 plan's
+    with torch.no_grad():
+        s32 = mutils.get_score_fn(sde, env['model'])(T(g['x'], dev), T(g['t'], dev), class_labels=T(g['labels'], dev)).cpu().numpy()
+    assert np.abs(s - s32).max() > 1e-4 * np.abs(ref).max()
+
+
+def test_bf16_is_refused_where_it_is_not_built(env):
+    """The 9x9 GTO-Halo plans are fp32 only: asking bf16 there fails loudly instead of silently computing in fp32."""
+    ge, dev = env['ge'], env['dev']
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    model, cfg, _ = ge.make_model(dev)
+    model.compute_dtype = 'bf16'
+    model._ctx.clear()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='bf16'):
+        mutils.get_score_fn(sde_lib.RVESDE(0.01, 5, N=1000), model)(torch.rand(2, 1, 9, 9, device=dev), torch.rand(2, device=dev), class_labels=torch.rand(2, 1, device=dev))
