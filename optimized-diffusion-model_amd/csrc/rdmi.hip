@@ -1224,6 +1224,7 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
         const int idx = b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv3", 0, 3 * C, "", bq, 3, &q, 1.f, -1, nullptr, nullptr, "", "");
         FOp& o = c->fprog[(size_t)idx];
         o.dst2_off = k.off; o.dst3_off = vt_off; o.dst3_rs = ps; o.split_C = C;
+        o.qkv1 = (std::getenv("RDMI_NO_QKV1") == nullptr && o.ntap == 1 && o.main_ph.nch == 4 && o.Cout_pad == 192 && C == 64 && o.mtiles <= 6) ? 1 : 0;
     }
     b.tfree(xn);
     const int p_off = b.alloc_top(p_bytes);

@@ -92,6 +92,7 @@ struct FOp {
     // (samp < 0: the low-resolution section -- tensors are [S * hw rows][C], row r belongs to sample r >> hw_shift, so every
     // streamed weight fragment feeds S samples).  hw_shift = log2(rows per sample) for multi-sample ops (hw is 4 or 16).
     int samp, hw_shift;
+    int qkv1;                                     // CONV dst_kind 3: run as the single-pass q/k/v projection (fconv_qkv)
 };
 
 struct UnetArgs {
@@ -646,6 +647,72 @@ __device__ __forceinline__ void fconv_gn_apply(const OpW& w, int mt0, int WM, in
         }
 }
 
+// The fused q/k/v projection of an attention block (dst_kind 3: one 1x1 conv with Cout = 3C, K = C = 64) in ONE pass per wave:
+// the generic path gives each wave its three column tiles (the q, k and v tile of its column offset) as three separate passes of
+// four k-steps each -- three prologues and epilogues around 48 MFMAs.  Here the wave loads its 12 weight fragments up front, reads
+// each A fragment once for all three column tiles and runs the 144 MFMAs back to back into 9 accumulator tiles.
+// Preconditions (host: FOp::qkv1 set by the planner): ntap == 1, nch == 4, Cout_pad == 12 tiles (WN = 4, WM = 2), mtiles <= 6.
+__device__ __forceinline__ void fconv_qkv(const OpW& w, const UnetArgs& u, int wave, int lane) {
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int wn = wave & 3, wm = wave >> 2;
+    const int o_rows = OPI(w, rows), mtiles = OPI(w, mtiles), o_Cout_pad = OPI(w, Cout_pad);
+    const int m_lds = OPI(w, main_ph.lds_off), m_rs = OPI(w, main_ph.rs);
+    const float* m_w = OPP(w, const float, main_ph.w);
+    const float* o_bias = OPP(w, const float, bias);
+    const float o_scale = OPF(w, scale);
+    const int sc_ = OPI(w, split_C), o_dst = OPI(w, dst_off), o_dst2 = OPI(w, dst2_off), o_dst3 = OPI(w, dst3_off), o_dst_rs = OPI(w, dst_rs), rs3 = OPI(w, dst3_rs);
+    const short* tab = reinterpret_cast<const short*>(rdmi_lds + opw_at(w, (int)(offsetof(FOp, tab_off) / 4)));
+    const size_t bstride = (size_t)o_Cout_pad * 16;
+    f32x4 bf[3][4];
+    float add[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int col = (wn + 4 * c) * 16 + lrow;
+        add[c] = ldg1(o_bias + col);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) bf[c][ch] = ldg4(m_w + (size_t)col * 16 + kq * 4 + (size_t)ch * bstride);
+    }
+    int abase[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) abase[i] = arow(tab, min((wm + 2 * i) * 16 + lrow, mtiles * 16 - 1), m_lds, m_rs, u.zero_off) + kq * 16;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        f32x4 af[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[i][c] = mfma16(af[i][j], bf[c][ch][j], acc[i][c]);
+    }
+    // epilogue: q -> dst, k -> dst2 ([row][col]), v -> dst3 transposed ([col][row], all padded rows written)
+    const int lc = wn * 16 + lrow;                       // column inside q / k / v (split_C = 64 = 4 tiles: tile wn of each)
+    (void)sc_;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int mt = wm + 2 * i;
+        if (mt >= mtiles) continue;
+        const int row0 = mt * 16 + kq * 4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float* dstp = lds_f(c == 0 ? o_dst : o_dst2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < o_rows) dstp[(row0 + r) * o_dst_rs + lc] = (acc[i][c][r] + add[c]) * o_scale;
+        }
+        f32x4 v = acc[i][2];
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] + add[2]) * o_scale;
+        *reinterpret_cast<f32x4*>(lds_f(o_dst3) + lc * rs3 + row0) = v;
+    }
+}
+
 template <bool DIAG, bool MS>
 __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0, int wave, int lane, long long* fine) {
     const int ntiles = OPI(w, Cout_pad) >> 4, mtiles = OPI(w, mtiles);
@@ -654,6 +721,7 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
     const int wn = wave & (WN - 1), wm = wave >> lWN;
     const int o_Cout = OPI(w, Cout), o_dense = OPI(w, dense_off);
     const float* o_bias = OPP(w, const float, bias); const float* o_bias2 = OPP(w, const float, bias2);
+    if (OPI(w, dst_kind) == 3 && OPI(w, qkv1)) { fconv_qkv(w, u, wave, lane); return; }
     const bool fused_gn = OPI(w, dst_kind) == 0 && OPI(w, gn_off) >= 0;      // host guarantees: then every wave has at most one pass below
     const int o_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
     const float* dense_base = u.dense + (size_t)o_dense;
