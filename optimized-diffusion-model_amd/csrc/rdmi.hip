@@ -694,6 +694,7 @@ int finish_tiled_plan(rdmi_ctx* c) {
             a.wpk = c->d_w + l.w_off;
             a.dense = l.use_dense ? c->d_dense : nullptr;
             if (tconv_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_lds_bytes(a));
+            if (tconv_trv(a) * tconv_wl(a) * 8 > TC_MAXS * RDMI_THREADS) return fail("tiled conv %s: window of %d pixels exceeds the register staging (%d float4 per work-item)", l.name.c_str(), tconv_trv(a) * tconv_wl(a), TC_MAXS);
         } else if (l.kind == 1) {
             l.sA = tl_ptr(c, l.oA); l.sB = tl_ptr(c, l.oB); l.stats = tl_ptr(c, l.oStats);
         } else if (l.kind == 2) {

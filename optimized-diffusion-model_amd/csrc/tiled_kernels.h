@@ -49,35 +49,72 @@ __host__ __device__ inline size_t tconv_lds_bytes(const TConvArgs& a) { return (
 // One MFMA per (tap, row tile, column tile, 32-channel slab) replaces eight fp32 ones at 1/16 of their cycles.
 __host__ __device__ inline size_t tconv_bf16_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * 40 * 2; }
 
-template <bool BF16>
-__device__ __forceinline__ void tconv_stage(const TConvArgs& a, int n, int c0, int vy0, int vx0, int Wl, int npix, int tid) {
-    const int Cin = a.CA + a.CB;
-    for (int i = tid; i < npix * 8; i += RDMI_THREADS) {
-        const int p = i >> 3, q = i & 7;
+// Staging is split in two so that the global loads of the NEXT 32-channel slab are in flight while the MFMAs of the current one
+// run: tconv_fetch issues this work-item's (up to TC_MAXS) 16-byte loads of a slab into registers -- the per-element window
+// geometry (source pixel or "outside") is slab-independent and computed once -- and tconv_commit applies GroupNorm + SiLU from
+// the per-(sample, group) statistics, converts (bf16 plan) and writes the LDS window.
+#define TC_MAXS 10                      // ceil(297 window pixels * 8 float4 / 256 work-items)
+struct TcGeom { long sp[TC_MAXS]; };    // source pixel index of staged element k (-1: outside the image or beyond the window)
+
+__device__ __forceinline__ void tconv_geom(const TConvArgs& a, int n, int vy0, int vx0, int Wl, int npix, int tid, TcGeom& g) {
+#pragma unroll
+    for (int k = 0; k < TC_MAXS; ++k) {
+        const int i = tid + k * RDMI_THREADS;
+        const int p = i >> 3;
         const int ry = p / Wl, rx = p - ry * Wl;
         const int vy = vy0 + ry, vx = vx0 + rx;
-        const int c = c0 + q * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv && c < Cin) {
+        long sp = -1;
+        if (i < npix * 8 && vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv) {
             const int sy = a.up ? (vy >> 1) : vy, sx = a.up ? (vx >> 1) : vx;
-            const size_t sp = (size_t)n * a.Ha * a.Wa + (size_t)sy * a.Wa + sx;
+            sp = (long)n * a.Ha * a.Wa + (long)sy * a.Wa + sx;
+        }
+        g.sp[k] = sp;
+    }
+}
+
+__device__ __forceinline__ void tconv_fetch(const TConvArgs& a, const TcGeom& g, int c0, int tid, f32x4 (&raw)[TC_MAXS]) {
+    const int Cin = a.CA + a.CB;
+    const int c = c0 + (tid & 7) * 4;                       // work-item's channel quad (i & 7 == tid & 7 for every k)
+#pragma unroll
+    for (int k = 0; k < TC_MAXS; ++k) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (g.sp[k] >= 0 && c < Cin) {
             if (c < a.CA) {
-                const float* ptr = a.srcA + sp * a.CA + c;
+                const float* ptr = a.srcA + (size_t)g.sp[k] * a.CA + c;
                 if ((a.CA & 3) == 0) v = *reinterpret_cast<const f32x4*>(ptr);
                 else
                     for (int j = 0; j < 4; ++j)
                         if (c + j < a.CA) v[j] = ptr[j];
             } else {
-                v = *reinterpret_cast<const f32x4*>(a.srcB + sp * a.CB + (c - a.CA));
+                v = *reinterpret_cast<const f32x4*>(a.srcB + (size_t)g.sp[k] * a.CB + (c - a.CA));
             }
-            if (a.stats) {
-                const int g = c / a.Cg;
-                const float mean = a.stats[((size_t)n * a.G + g) * 2], rstd = a.stats[((size_t)n * a.G + g) * 2 + 1];
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
-                for (int j = 0; j < 4; ++j) {
-                    const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
-                    v[j] = a.act ? silu_f(y) : y;
-                }
+        }
+        raw[k] = v;
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g, int n, int c0, int npix, int tid, const f32x4 (&raw)[TC_MAXS]) {
+    const int Cin = a.CA + a.CB;
+    const int q = tid & 7, c = c0 + q * 4;
+    float mean = 0.f, rstd = 1.f;
+    f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+    const bool gn = a.stats != nullptr && c < Cin;
+    if (gn) {
+        const int grp = c / a.Cg;
+        mean = a.stats[((size_t)n * a.G + grp) * 2]; rstd = a.stats[((size_t)n * a.G + grp) * 2 + 1];
+        gm = *reinterpret_cast<const f32x4*>(a.gamma + c); bt = *reinterpret_cast<const f32x4*>(a.beta + c);
+    }
+#pragma unroll
+    for (int k = 0; k < TC_MAXS; ++k) {
+        const int i = tid + k * RDMI_THREADS;
+        if (i >= npix * 8) break;
+        const int p = i >> 3;
+        f32x4 v = raw[k];
+        if (gn && g.sp[k] >= 0) {                           // padding stays zero: the conv pads the ACTIVATED tensor
+            for (int j = 0; j < 4; ++j) {
+                const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
+                v[j] = a.act ? silu_f(y) : y;
             }
         }
         if (BF16) {
@@ -123,9 +160,14 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
     }
     const size_t bstride = (size_t)a.Cout_pad * (BF16 ? 32 : 16);
     const int nk = BF16 ? (a.Cv >> 5) : (a.Cv >> 4);                  // weight k-slabs per tap
+    TcGeom geom;
+    tconv_geom(a, n, vy0, vx0, Wl, npix, tid, geom);
+    f32x4 raw[TC_MAXS];
+    tconv_fetch(a, geom, 0, tid, raw);
     for (int c0 = 0; c0 < a.Cv; c0 += 32) {
-        tconv_stage<BF16>(a, n, c0, vy0, vx0, Wl, npix, tid);
+        tconv_commit<BF16>(a, geom, n, c0, npix, tid, raw);
         __syncthreads();
+        if (c0 + 32 < a.Cv) tconv_fetch(a, geom, c0 + 32, tid, raw);          // next slab's loads fly under this slab's MFMAs
         for (int t = 0; t < a.ntap; ++t) {
             const int toff = a.ntap == 1 ? 0 : (t / 3) * Wl + (t % 3);
             if (BF16) {

@@ -32,7 +32,7 @@ if len(sys.argv) > 1:
     t0 = time.time(); x, nfe = fn(m2, weight=0.0, class_labels=lab); torch.cuda.synchronize(); dt = time.time() - t0
     print(f'B={B} N={N}: {dt/(N-1)*1e3:.2f} ms/update -> {B/(dt/(N-1)*999):.3f} traj/s at 1000 scales; finite {bool(torch.isfinite(x).all())}')
 if os.environ.get('CIFAR_PROF'):
-    B = 16
+    B = int(os.environ['CIFAR_PROF'])
     x = torch.rand(B, 3, 32, 32, device=dev); t = torch.full((B,), 0.5, device=dev); lab = torch.zeros(B, 1, device=dev)
     fn = mutils.get_cf_score_fn(sde, model, lab, 0.0)
     with torch.no_grad():

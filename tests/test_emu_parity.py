@@ -215,7 +215,7 @@ def test_param_rebinding_is_seen(env):
     from rdmi.models.ema import ExponentialMovingAverage
     model = env['ge'].make_model('cpu')[0]
     sde = sde_lib.RVESDE(0.01, 5, N=1000)
-    x, t, lab = torch.rand(2, 1, 9, 9), torch.tensor([0.3, 0.8]), torch.rand(2, 1)
+    x, t, lab = torch.rand(1, 1, 9, 9), torch.tensor([0.3]), torch.rand(1, 1)
     fn = mutils.get_score_fn(sde, model)
     with torch.no_grad():
         a = fn(x, t, class_labels=lab)
@@ -370,11 +370,12 @@ def check_train_w0_against_reference(out, g, nsteps, rtol_loss=2e-3):
 
 
 def test_optimizer_and_ema_updates_match_reference(env, golden):
-    """The optimizer / EMA half of losses.get_step_fn at full learning rate (fixture train_step_w0.npz, warmup=0): two
-    steps on the emulator (the GPU test runs all three recorded steps)."""
+    """The optimizer / EMA half of losses.get_step_fn at full learning rate (fixture train_step_w0.npz, warmup=0): one step on
+    the emulator -- clipping, Adam's bias-corrected first update and the EMA shadow all move at full size -- while the GPU test
+    runs all three recorded steps (second moments, later bias corrections)."""
     g = golden('train_step_w0.npz')
-    out = _train_steps_w0(env['ge'], 'cpu', g, 2)
-    check_train_w0_against_reference(out, g, 2)
+    out = _train_steps_w0(env['ge'], 'cpu', g, 1)
+    check_train_w0_against_reference(out, g, 1)
 
 
 def test_fused_optimizer_step_equals_torch(emu):
