@@ -162,7 +162,7 @@ struct rdmi_ctx {
     };
     // tiled plan (shapes whose samples do not fit one workgroup: csrc/tiled_kernels.h)
     struct TLaunch {
-        int kind = 0;                 // 0 conv, 1 GroupNorm statistics, 2 batched GEMM, 3 softmax, 4 transpose
+        int kind = 0;                 // 0 conv, 1 GroupNorm statistics (pass over the tensor), 2 batched GEMM, 3 softmax, 4 transpose, 5 statistics from channel sums
         std::string name;
         TConvArgs conv{}; int nmt = 4;
         const float *sA = nullptr, *sB = nullptr; int CA = 0, CB = 0, HW = 0, G = 0; float* stats = nullptr;     // kind 1
@@ -510,7 +510,7 @@ int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, in
 struct TiledBuilder {
     rdmi_ctx* c; Builder& b;
     size_t top = 0;                                   // floats per sample allocated so far
-    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; };
+    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0; };   // cs: per-tile channel sums of the producer
     TT talloc(int C, int H, int W) { TT t; t.off = top; t.C = C; t.H = H; t.W = W; t.valid = true; top += ((size_t)C * H * W + 63) & ~(size_t)63; return t; }
     static int pad32(int a) { return (a + 31) & ~31; }
 
@@ -533,6 +533,14 @@ struct TiledBuilder {
     TT stats(const std::string& name, const TT& A, const TT* B) {
         const int C = A.C + (B ? B->C : 0), G = std::min(C / 4, 32);
         TT st = talloc(2 * G, 1, 1);
+        if (A.cs != (size_t)-1 && (!B || B->cs != (size_t)-1) && std::getenv("RDMI_TILED_STATS_PASS") == nullptr) {
+            // statistics from the channel sums the producing convs left behind: no pass over the tensors
+            rdmi_ctx::TLaunch f; f.kind = 5; f.name = name + ".stats";
+            f.oA = A.cs; f.oB = B ? B->cs : rdmi_ctx::TLaunch::NONE; f.CA = A.C; f.CB = B ? B->C : 0; f.HW = A.H * A.W; f.G = G;
+            f.tL = A.tiles; f.tC = B ? B->tiles : 0; f.oStats = st.off;
+            c->tl.push_back(f);
+            return st;
+        }
         rdmi_ctx::TLaunch l; l.kind = 1; l.name = name + ".stats";
         l.oA = A.off; l.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; l.CA = A.C; l.CB = B ? B->C : 0; l.HW = A.H * A.W; l.G = G;
         l.oStats = st.off;
@@ -553,7 +561,14 @@ struct TiledBuilder {
         a.out_scale = scale;
         a.Cout = cout; a.Cout_pad = pad16(cout);
         TT out = talloc(cout, a.Ho, a.Wo);
+        size_t cs_off = rdmi_ctx::TLaunch::NONE;
+        if (!final_out && cout % 4 == 0) {
+            out.tiles = ceil_div(a.Ho, a.TR);
+            TT cs = talloc(2 * cout * out.tiles, 1, 1);
+            out.cs = cs_off = cs.off;
+        }
         rdmi_ctx::TLaunch l; l.kind = 0; l.name = name; l.conv = a;
+        l.oC = cs_off;
         l.oA = A.off; l.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; l.oStats = st ? st->off : rdmi_ctx::TLaunch::NONE;
         l.oResid = resid ? resid->off : rdmi_ctx::TLaunch::NONE; l.oOut = out.off;
         l.nmt = (a.TR * a.Wo > 16) ? 4 : 1;
@@ -693,6 +708,7 @@ int finish_tiled_plan(rdmi_ctx* c) {
             a.out = l.out_is_final ? c->t_out : tl_ptr(c, l.oOut);
             a.wpk = c->d_w + l.w_off;
             a.dense = l.use_dense ? c->d_dense : nullptr;
+            a.chsum = tl_ptr(c, l.oC);
             if (tconv_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_lds_bytes(a));
             if (tconv_trv(a) * tconv_wl(a) * 8 > TC_MAXS * RDMI_THREADS) return fail("tiled conv %s: window of %d pixels exceeds the register staging (%d float4 per work-item)", l.name.c_str(), tconv_trv(a) * tconv_wl(a), TC_MAXS);
         } else if (l.kind == 1) {
@@ -701,6 +717,8 @@ int finish_tiled_plan(rdmi_ctx* c) {
             l.gemm.A = tl_ptr(c, l.oA, l.dA); l.gemm.B = tl_ptr(c, l.oB, l.dB); l.gemm.C = tl_ptr(c, l.oC);
         } else if (l.kind == 3) {
             l.sm = tl_ptr(c, l.oA);
+        } else if (l.kind == 5) {
+            l.sA = tl_ptr(c, l.oA); l.sB = tl_ptr(c, l.oB); l.stats = tl_ptr(c, l.oStats);
         } else {
             l.tsrc = tl_ptr(c, l.oA); l.tdst = tl_ptr(c, l.oOut);
         }
@@ -1762,6 +1780,9 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             ProfScope ps(c, s, a.compute_dtype == 1 ? "bgemm_nt_bf16_kernel" : "bgemm_nt_kernel", l.flops_per_sample * NB);
             if (a.compute_dtype == 1) hipLaunchKernelGGL(bgemm_nt_bf16_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
             else hipLaunchKernelGGL(bgemm_nt_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
+        } else if (l.kind == 5) {
+            ProfScope ps(c, s, "gn_finalize_kernel", 0);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NB), dim3(64), 0, s, l.sA, l.sB, l.CA, l.CB, l.tL, l.tC, l.HW, l.G, 1e-6f, l.stats);
         } else if (l.kind == 3) {
             const long rows = l.rows_per_sample * NB;
             ProfScope ps(c, s, "softmax_rows_kernel", 0);

@@ -33,6 +33,8 @@ struct TConvArgs {
     float out_scale;
     const float* sig; int sig_is_time, sig_mod; float smin, ratio;   // scale_by_sigma: out /= sigma[n % sig_mod] (null: off)
     float* out; int Cout, Cout_pad;
+    float* chsum;                           // null or [n][tiles per image][Cout][2]: per-channel (sum, sum of squares) of this tile's outputs,
+                                            // from which the consumer's GroupNorm statistics are formed (gn_finalize_kernel): no extra pass over the tensor
     int NB;
 };
 
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
         if (col >= a.Cout) continue;
         float add = a.bias ? a.bias[col] : 0.f;
         if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NMT; ++i)
 #pragma unroll
@@ -223,10 +226,41 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
                     const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
                     float v = acc[i][cc][r] + add;
                     if (a.resid) v += a.resid[o];
-                    a.out[o] = v * scale;
+                    v *= scale;
+                    a.out[o] = v;
+                    s1 += v; s2 += v * v;
                 }
             }
+        if (a.chsum) {            // this lane's column over its rows, then over the four k-groups that hold the other rows of the tile
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (kq == 0) {        // every (sample, tile, column) has exactly one writer: no atomics, run-to-run identical
+                float* cs = a.chsum + (((size_t)n * tiles_per_img + tile) * a.Cout + col) * 2;
+                cs[0] = s1; cs[1] = s2;
+            }
+        }
     }
+}
+
+// GroupNorm statistics of concat(A, B) from the producers' per-tile channel sums: stats[n][g] = (mean, rstd) with the single-pass
+// variance E[x^2] - mean^2 (fp32; activations are O(1)).  grid = NB, one work-item per group; tiles are added in a fixed order.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ csA, const float* __restrict__ csB, int CA, int CB, int tilesA, int tilesB,
+                                                         int HW, int G, float eps, float* __restrict__ stats) {
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    const int C = CA + CB, Cg = C / G;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+        const bool inA = c < CA;
+        const float* cs = inA ? csA : csB;
+        const int Cx = inA ? CA : CB, cx = inA ? c : c - CA, tiles = inA ? tilesA : tilesB;
+        for (int t = 0; t < tiles; ++t) { const float* p = cs + (((size_t)n * tiles + t) * Cx + cx) * 2; s1 += p[0]; s2 += p[1]; }
+    }
+    const float cnt = (float)(Cg * HW);
+    const float mean = s1 / cnt;
+    const float var = fmaxf(s2 / cnt - mean * mean, 0.f);
+    stats[((size_t)n * G + g) * 2] = mean;
+    stats[((size_t)n * G + g) * 2 + 1] = 1.0f / sqrtf(var + eps);
 }
 
 // mean / rstd of GroupNorm group g of sample n over concat(A, B): grid = (G, NB); two passes (exact like F.group_norm)
