@@ -58,6 +58,8 @@ struct ConvArgs {
     float out_scale, eps;
     int S, BN, Mpad;
     float drop_p; uint64_t drop_seed; uint32_t op_id;   // train mode: dropout after GN+SiLU (Dropout_0, RD/models/layerspp.py:204)
+    int bf16;                     // 1: wpk / wsc are the bf16 copies [tap][C/32][Cout_pad][32] and the MFMAs take bf16 operands (fp32 accumulate);
+                                  //    needs Cv % 32 == 0 and Csc % 32 == 0 (training with compute_dtype = bf16, BASELINE config #4)
     int dbg;                      // unused (kept so the argument block layout of recorded launches stays stable)
 };
 
@@ -108,7 +110,7 @@ __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const 
 
 // The GEMM + epilogue for a wave that owns NMT row tiles (compile-time) x NT column tiles.
 // B fragments (weights) stream from L2 through a PF-deep register ring; A fragments come from LDS.
-template <int WM, int WN, int WK, int NMT, int NT, int PF>
+template <int WM, int WN, int WK, int NMT, int NT, int PF, bool BF16 = false>
 __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __restrict__ X, const float* __restrict__ XS,
                                           const int* __restrict__ tabL, int rs, int rss, int wm, int wn, int wk,
                                           int lane, int wave, int n0, int co0) {
@@ -126,6 +128,77 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
 #pragma unroll
         for (int i = 0; i < NMT; ++i) trow[i] = ((wm + i * WM) * 16 + lrow) * tw;
 
+        if (BF16) {
+            // bf16 operands (v_mfma_f32_16x16x32_bf16): a step is 32 channels of one tap; the A fragment is 8 consecutive fp32 of the
+            // activated LDS row rounded to bf16 on the fly, the B fragment 16 bytes of the bf16 weight copy
+            auto afrag = [](const float* p) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(p), y = *reinterpret_cast<const f32x4*>(p + 4);
+                return u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+            };
+            {
+                const int nch = a.Cv >> 5;
+                const int nsteps = a.ntap * nch;
+                const size_t bstride = (size_t)a.Cout_pad * 32;
+                const bf16_t* Wl = reinterpret_cast<const bf16_t*>(a.wpk) + (size_t)(colbase + lrow) * 32 + kq * 8;
+                u32x4 bring[PF][NT];
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+                    if (wk + u * WK < nsteps) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) bring[u][t] = *reinterpret_cast<const u32x4*>(Wl + (size_t)(wk + u * WK) * bstride + t * 512);
+                    }
+                int ph = wk / nch, ch = wk - ph * nch;
+                int abase[NMT > 0 ? NMT : 1];
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs + kq * 8;
+                for (int q = wk; q < nsteps; q += PF * WK) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        const int qq = q + u * WK;
+                        if (qq < nsteps) {
+#pragma unroll
+                            for (int i = 0; i < NMT; ++i) {
+                                const u32x4 af = afrag(X + abase[i] + ch * 32);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) acc[i][t] = mfma16_bf16(af, bring[u][t], acc[i][t]);
+                            }
+                            if (qq + PF * WK < nsteps) {
+#pragma unroll
+                                for (int t = 0; t < NT; ++t)
+                                    bring[u][t] = *reinterpret_cast<const u32x4*>(Wl + (size_t)(qq + PF * WK) * bstride + t * 512);
+                            }
+                            ch += WK;
+                            if (ch >= nch) {
+                                ch -= nch; ++ph;
+                                if (ph < a.ntap) {
+#pragma unroll
+                                    for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs + kq * 8;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (a.Csc) {
+                const int nch = a.Csc >> 5;
+                const size_t bstride = (size_t)a.Cout_pad * 32;
+                const bf16_t* Wl = reinterpret_cast<const bf16_t*>(a.wsc) + (size_t)(colbase + lrow) * 32 + kq * 8;
+                int abase[NMT > 0 ? NMT : 1];
+#pragma unroll
+                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + a.ntap] * rss + kq * 8;
+                for (int ch = wk; ch < nch; ch += WK) {
+                    u32x4 bf[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const u32x4*>(Wl + (size_t)ch * bstride + t * 512);
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) {
+                        const u32x4 af = afrag(XS + abase[i] + ch * 32);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[i][t] = mfma16_bf16(af, bf[t], acc[i][t]);
+                    }
+                }
+            }
+        } else {
         // ---- conv phases: flattened step q = tap * nch + chunk; B for step q sits at wpk + q * bstride
         {
             const int nch = a.Cv >> 4;
@@ -205,6 +278,7 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
                 for (int t = 0; t < NT; ++t) bcur[t] = bnext[t];
             }
         }
+        }   // fp32 / bf16 operand paths
     }
 
     // ---- split-K across waves: reduce through LDS (the input tile is dead by now)
@@ -260,7 +334,7 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
     }
 }
 
-template <int WM, int WN, int WK, int MT, int NT, int PF>
+template <int WM, int WN, int WK, int MT, int NT, int PF, bool BF16 = false>
 __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
     static_assert(WK == 1 || MT == 1, "split-K waves all own the same single row tile");
@@ -345,7 +419,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
     const int nmt = mtiles > wm ? (mtiles - wm + WM - 1) / WM : 0;
 #define RDMI_CASE(K)                                                                                         \
     case K:                                                                                                  \
-        if (K <= MT) conv_gemm<WM, WN, WK, (K <= MT ? K : 0), NT, PF>(a, X, XS, tabL, rs, rss, wm, wn, wk, lane, wave, n0, co0); \
+        if (K <= MT) conv_gemm<WM, WN, WK, (K <= MT ? K : 0), NT, PF, BF16>(a, X, XS, tabL, rs, rss, wm, wn, wk, lane, wave, n0, co0); \
         break;
     switch (nmt) {
         RDMI_CASE(0) RDMI_CASE(1) RDMI_CASE(2) RDMI_CASE(3) RDMI_CASE(4) RDMI_CASE(5) RDMI_CASE(6)

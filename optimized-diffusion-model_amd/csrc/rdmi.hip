@@ -178,6 +178,8 @@ struct rdmi_ctx {
         double flops_per_sample = 0;
     };
     bool tiled = false;
+    bool in_train_forward = false;       // set around run_forward by rdmi_train_forward
+    bf16_t* d_w16 = nullptr;             // bf16 copies of the forward conv weights (training with compute_dtype = bf16)
     std::vector<TLaunch> tl;
     float *t_ws = nullptr, *t_xin = nullptr, *t_out = nullptr; size_t t_ws_per_sample = 0;
     std::vector<FusedProg> progs;
@@ -764,7 +766,6 @@ int build_plan(rdmi_ctx* c) {
     // Shapes beyond one workgroup per sample (more than 96 pixels, or more than one image channel: the CIFAR-shape model of
     // BASELINE config #5) run the spatially tiled plan; the GTO-Halo shapes keep the workgroup-resident / layer plans below.
     if (a.compute_dtype != 0 && a.compute_dtype != 1) return fail("compute_dtype=%d (0: fp32, 1: bf16)", a.compute_dtype);
-    if (a.compute_dtype == 1 && !(c->H * c->W > 96 || a.channels != 1)) return fail("compute_dtype=bf16 is built for the tiled plan only (samples of more than 96 pixels or several channels)");
     if (c->H * c->W > 96 || a.channels != 1) {
         try { if (int e = build_tiled_plan(c, b, L, dense_off)) return e; }
         catch (const std::exception& ex) { return fail("tiled plan: %s", ex.what()); }
@@ -1552,10 +1553,10 @@ void prof_collect(rdmi_ctx* c) {
     c->ev_used = 0;
 }
 
-template <int WM, int WN, int WK, int MT, int NT, int PF>
+template <int WM, int WN, int WK, int MT, int NT, int PF, bool BF16>
 int launch_conv_t(const ConvArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    auto k = conv_mfma_kernel<WM, WN, WK, MT, NT, PF>;
+    auto k = conv_mfma_kernel<WM, WN, WK, MT, NT, PF, BF16>;
     if (!attr_set) { HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     dim3 grid((unsigned)ceil_div(a.NB, a.S), (unsigned)(a.Cout_pad / a.BN));
     hipLaunchKernelGGL(k, grid, dim3(RDMI_THREADS), conv_lds_bytes(a), s, a);
@@ -1564,11 +1565,21 @@ int launch_conv_t(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_conv(int cfg, const ConvArgs& a, hipStream_t s) {
+    if (a.bf16) {
+        if ((a.Cv & 31) || (a.Csc & 31)) return fail("bf16 conv launch with %d / %d input channels (multiples of 32 needed)", a.Cv, a.Csc);
+        switch (cfg) {
+            case 0: return launch_conv_t<1, 4, 1, 6, 1, 2, true>(a, s);
+            case 1: return launch_conv_t<2, 2, 1, 3, 1, 3, true>(a, s);
+            case 2: return launch_conv_t<1, 2, 2, 1, 1, 6, true>(a, s);
+            case 3: return launch_conv_t<4, 1, 1, 2, 1, 4, true>(a, s);
+        }
+        return fail("bad conv cfg %d", cfg);
+    }
     switch (cfg) {
-        case 0: return launch_conv_t<1, 4, 1, 6, 1, 2>(a, s);
-        case 1: return launch_conv_t<2, 2, 1, 3, 1, 3>(a, s);
-        case 2: return launch_conv_t<1, 2, 2, 1, 1, 6>(a, s);
-        case 3: return launch_conv_t<4, 1, 1, 2, 1, 4>(a, s);
+        case 0: return launch_conv_t<1, 4, 1, 6, 1, 2, false>(a, s);
+        case 1: return launch_conv_t<2, 2, 1, 3, 1, 3, false>(a, s);
+        case 2: return launch_conv_t<1, 2, 2, 1, 1, 6, false>(a, s);
+        case 3: return launch_conv_t<4, 1, 1, 2, 1, 4, false>(a, s);
     }
     return fail("bad conv cfg %d", cfg);
 }
@@ -1695,6 +1706,9 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     }
     }
     HIP_OK(hipGetLastError());
+    if (a.compute_dtype == 1 && !c->tiled && !c->in_train_forward)
+        return fail("compute_dtype=bf16 on this shape is built for the TRAINING step only (model.train_dtype = 'bf16'); sampling and evaluation of the "
+                    "GTO-Halo model run the exact-fp32 plans");
     if (c->tiled) return run_tiled(c, f.x, f.x_mod, f.sig, f.sig_mod, f.t_is_time, f.t_scalar, f.smin, f.ratio, f.out, f.NB, f.dense_rows, s);
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
     const rdmi_ctx::FusedProg* fq = (c->use_fused && !c->debug_taps) ? c->pick(f.NB) : nullptr;
@@ -1878,7 +1892,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         delete T;
     }
     for (auto& q : c->progs) for (void* p : {(void*)q.d_fprog, (void*)q.d_ftabs, (void*)q.d_spill}) if (p) hipFree(p);
-    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all, c->t_ws, c->t_xin, c->t_out};
+    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all, c->t_ws, c->t_xin, c->t_out, c->d_w16};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete c;

@@ -93,6 +93,50 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
         }
         c->debug_taps = true;            // the layer plan is now the only valid plan for this context (fused plan spills differently)
     }
+    // ---- compute_dtype = bf16 (BASELINE config #4): bf16 weight copies for every conv whose channel counts allow the 32-wide
+    //      bf16 MFMA step (all but the 1-channel input conv); the fp32 parameters stay the master copy, accumulation is fp32
+    const bool bf = c->arch.compute_dtype == 1;
+    if (bf) {
+        size_t w16 = 0;                                      // bf16 elements
+        auto alloc16 = [&](size_t n) { size_t o = w16; w16 += (n + 127) & ~(size_t)127; return o; };
+        std::vector<std::pair<size_t, size_t>> fix;          // (job index, element offset)
+        for (auto& op : c->ops) {
+            if (op.kind != OP_CONV) continue;
+            ConvArgs& ca = op.conv;
+            const ConvSpec& sp = op.spec;
+            if ((ca.Cv & 31) || (ca.Csc & 31)) continue;
+            const int Cin = sp.CA + sp.CB;
+            {
+                PackJob j{};
+                j.Cin = Cin; j.Cout = sp.Cout; j.Kpad = ca.Cv; j.Npad = ca.Cout_pad; j.n_off = 0; j.ntap = 9; j.s_co = (long)Cin * 9; j.s_ci = 9; j.s_t = 1; j.kind = 2;
+                fix.push_back({c->jobs.size(), alloc16((size_t)9 * ca.Cv * ca.Cout_pad)});
+                c->jobs.push_back(j); c->job_param.push_back(c->pindex.at(sp.conv + ".weight"));
+            }
+            if (ca.Csc) {
+                const int Csc = sp.CscA + sp.CscB;
+                PackJob j{};
+                j.Cin = Csc; j.Cout = sp.Cout; j.Kpad = ca.Csc; j.Npad = ca.Cout_pad; j.n_off = 0; j.ntap = 1; j.s_co = 1; j.s_ci = sp.Cout; j.s_t = 0; j.kind = 2;
+                fix.push_back({c->jobs.size(), alloc16((size_t)ca.Csc * ca.Cout_pad)});
+                c->jobs.push_back(j); c->job_param.push_back(c->pindex.at(sp.nin + ".W"));
+            }
+            ca.bf16 = 1;
+        }
+        HIP_OK(hipMalloc((void**)&c->d_w16, std::max<size_t>(w16, 64) * sizeof(bf16_t)));
+        HIP_OK(hipMemset(c->d_w16, 0, std::max<size_t>(w16, 64) * sizeof(bf16_t)));
+        size_t k = 0;
+        for (auto& op : c->ops) {
+            if (op.kind != OP_CONV || !op.conv.bf16) continue;
+            c->jobs[fix[k].first].dst = reinterpret_cast<float*>(c->d_w16 + fix[k].second);
+            op.conv.wpk = reinterpret_cast<const float*>(c->d_w16 + fix[k].second); ++k;
+            if (op.conv.Csc) {
+                c->jobs[fix[k].first].dst = reinterpret_cast<float*>(c->d_w16 + fix[k].second);
+                op.conv.wsc = reinterpret_cast<const float*>(c->d_w16 + fix[k].second); ++k;
+            }
+        }
+        if (c->d_jobs) (void)hipFree(c->d_jobs);
+        HIP_OK(hipMalloc((void**)&c->d_jobs, c->jobs.size() * sizeof(PackJob)));
+        c->packed_valid = false;
+    }
     T.poff.resize(c->params.size());
     T.ptotal = 0;
     for (size_t i = 0; i < c->params.size(); ++i) { T.poff[i] = T.ptotal; T.ptotal += c->params[i].numel; }
@@ -163,6 +207,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             j.dst = reinterpret_cast<float*>(b.wT_off);
             j.Cin = sp.Cout; j.Cout = Cin; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 9;
             j.s_co = 9; j.s_ci = (long)Cin * 9; j.s_t = 1; j.kind = 0;     // "co" of the job = ci of W, "ci" of the job = co of W
+            if (bf && (d.Cv & 31) == 0) { j.kind = 2; d.bf16 = 1; }
             T.jobs.push_back(j); T.job_param.push_back(b.p_w);
         }
         if (b.has_sc) {
@@ -180,6 +225,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             j.dst = reinterpret_cast<float*>(b.wscT_off);
             j.Cin = sp.Cout; j.Cout = Csc; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 1;
             j.s_co = sp.Cout; j.s_ci = 1; j.s_t = 0; j.kind = 0;            // NIN W [in=Csc][out=Cout]: job "co" = in, job "ci" = out
+            if (bf && (d.Cv & 31) == 0) { j.kind = 2; d.bf16 = 1; }
             T.jobs.push_back(j); T.job_param.push_back(b.p_wsc);
         }
         // inverse nearest maps for the scatter of gradients back to mapped sources
@@ -271,7 +317,9 @@ int rdmi_train_forward(rdmi_ctx* c, const float* x, const float* sigma, const fl
     FwdIn f{x, 0, sigma, 0, 0.f, 0, 0.f, 0.f, labels, B, out, B};
     const bool keep = c->use_fused;
     c->use_fused = false;
+    c->in_train_forward = true;
     int e = run_forward(c, f, s);
+    c->in_train_forward = false;
     c->use_fused = keep;
     for (auto& op : c->ops) if (op.kind == OP_CONV) op.conv.drop_p = 0.f;
     return e;

@@ -120,6 +120,11 @@ class NCSNpp(nn.Module):
         self.compute_dtype = str(getattr(m, 'compute_dtype', 'f32'))
         if self.compute_dtype not in ('f32', 'bf16'):
             raise NotImplementedError(f'compute_dtype {self.compute_dtype!r}: f32 or bf16')
+        # 'bf16': the TRAINING step's convolutions (forward, data gradient) take bf16 MFMA operands from bf16 weight copies; fp32 master
+        # weights, fp32 accumulation, fp32 optimizer (BASELINE config #4).  Sampling / evaluation are not affected.
+        self.train_dtype = str(getattr(m, 'train_dtype', 'f32'))
+        if self.train_dtype not in ('f32', 'bf16'):
+            raise NotImplementedError(f'train_dtype {self.train_dtype!r}: f32 or bf16')
         # what the HIP plan implements; anything else fails here, loudly, not in a fallback
         if m.embedding_type != 'fourier':
             raise NotImplementedError('Only fourier embedding supported')          # as RD/models/ncsnpp.py:100
@@ -202,8 +207,12 @@ class NCSNpp(nn.Module):
         if ctx is None or ctx.max_batch < model_batch:
             if ctx is not None:
                 ctx.close()
-            ctx = _native.Context(self._arch(), max(model_batch, 16), H, W, device)
+            arch = self._arch()
+            if self.train_dtype == 'bf16':
+                arch.compute_dtype = 1
+            ctx = _native.Context(arch, max(model_batch, 16), H, W, device)
             ctx.enable_training()
+            ctx.train_dtype = self.train_dtype
             self._ctx[key] = ctx
         ctx.bind((n, t) for n, t in self.state_dict(keep_vars=True).items())
         return ctx
