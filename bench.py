@@ -251,6 +251,8 @@ def variants(ge, dev, args, labels):
     out['cifar_b64'] = cifar_variant(ge, dev, 64)
     out['cifar_b64_bf16'] = cifar_variant(ge, dev, 64, dtype='bf16')
     out['train_b128'] = train_variant(ge, dev, 128)
+    out['train_b128_bf16'] = train_variant(ge, dev, 128, dtype='bf16')
+    out['train_b4096_bf16'] = train_variant(ge, dev, 4096, dtype='bf16', steps=5)
     return out
 
 
@@ -277,12 +279,13 @@ def cifar_variant(ge, dev, B, N=5, dtype='f32'):
             'plan': model._ctx[(str(dev), 32, 32)].path_info()}
 
 
-def train_variant(ge, dev, B, steps=10):
+def train_variant(ge, dev, B, steps=10, dtype='f32'):
     """BASELINE config #4 shape: losses.get_step_fn(train=True) -- HIP forward (dropout 0.2, label drop 0.5) + loss + HIP
     backward + clip + Adam + EMA -- at batch B.  FLOP = 3 x forward (forward, data gradient, weight gradient)."""
     from rdmi import losses, sde_lib
     from rdmi.models.ema import ExponentialMovingAverage
     model, cfg, _ = ge.make_model(dev)
+    model.train_dtype = dtype          # 'bf16': bf16 weight copies + bf16 MFMA operands in fwd / dgrad / wgrad, fp32 accumulate and master weights
     model.train()
     sde = sde_lib.RVESDE(0.01, 5, N=1000)
     opt = losses.get_optimizer(cfg, model.parameters())
@@ -300,8 +303,9 @@ def train_variant(ge, dev, B, steps=10):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     assert bool(torch.isfinite(loss.detach()))
     tf = 3 * GFLOP_PER_FORWARD * B / dt / 1e3
-    return {'ms_per_step': 1e3 * dt, 'samples_per_s': B / dt, 'batch': B, 'dtype': getattr(model, 'train_dtype', 'f32'), 'tflops': tf,
-            'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'loss': float(loss.detach()),
+    return {'ms_per_step': 1e3 * dt, 'samples_per_s': B / dt, 'batch': B, 'dtype': dtype, 'tflops': tf,
+            'frac': tf / (PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else 2500.0), 'peak_tflops': PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else 2500.0,
+            'loss': float(loss.detach()),
             'what': 'train-mode forward + score-matching loss + backward + clip_grad_norm_ + Adam + EMA, steps timed back to back'}
 
 

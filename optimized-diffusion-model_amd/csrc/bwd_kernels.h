@@ -193,6 +193,7 @@ struct WgradArgs {
     int ksplit;            // number of sample slices
     int S;                 // samples per staged chunk: S*HWv <= 255, S*HWo <= 128
     long s_co, s_ci, s_t;  // strides of dW
+    int bf16;              // 1: v_mfma_f32_16x16x32_bf16 over 32 staged rows per step (operands rounded to bf16 as they leave LDS, fp32 accumulate)
 };
 #define WG_AS 40
 #define WG_GS 72
@@ -200,17 +201,17 @@ __host__ __device__ inline int wgrad_chunk(int HWv, int HWo) {
     int s = 128 / HWo; if (255 / HWv < s) s = 255 / HWv;
     return s < 1 ? 1 : s;
 }
-__host__ __device__ inline size_t wgrad_lds_bytes(int HWv, int HWo, int S) {
-    const int RI = S * HWv, RO4 = (S * HWo + 3) & ~3;
+__host__ __device__ inline size_t wgrad_lds_bytes(int HWv, int HWo, int S, int bf16 = 0) {
+    const int RI = S * HWv, RO4 = bf16 ? ((S * HWo + 31) & ~31) : ((S * HWo + 3) & ~3);
     const size_t stage = (size_t)(RI + 1) * WG_AS + (size_t)RO4 * WG_GS + (size_t)RO4 * 4, flush = (size_t)64 * (32 * 9 + 1);
     return (stage > flush ? stage : flush) * 4;
 }
 
-template <int NTAP>
+template <int NTAP, bool BF16 = false>
 __global__ __launch_bounds__(RDMI_THREADS) void wgrad_mfma_kernel(WgradArgs a) {
     constexpr int NA = 8, NG = 8;   // float4 slots per work-item: 255 rows x 8 / 256, 128 rows x 16 / 256
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kq = lane >> 4;
-    const int S = a.S, RI = S * a.HWv, RO = S * a.HWo, RO4 = (RO + 3) & ~3;
+    const int S = a.S, RI = S * a.HWv, RO = S * a.HWo, RO4 = BF16 ? ((RO + 31) & ~31) : ((RO + 3) & ~3);   // staged G rows (bf16: whole 32-row MFMA steps)
     float* Al = reinterpret_cast<float*>(rdmi_lds);            // [RI + 1][WG_AS]; row RI = zeros
     float* Gl = Al + (RI + 1) * WG_AS;                         // [RO4][WG_GS]
     uint32_t* rt = reinterpret_cast<uint32_t*>(Gl + RO4 * WG_GS);   // [RO4][4]: byte t = staged ACT row of (row, tap t)
@@ -279,6 +280,38 @@ __global__ __launch_bounds__(RDMI_THREADS) void wgrad_mfma_kernel(WgradArgs a) {
         }
         __syncthreads();
         if (n0 + S < n_hi) fetch(n0 + S);
+        if (BF16) {
+            for (int ks = 0; ks < RO4; ks += 32) {
+                const int r0 = ks + kq * 8;                         // this lane's 8 consecutive k (staged G rows)
+                float g0[8], g1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g0[j] = Gl[(r0 + j) * WG_GS + gcol]; g1[j] = Gl[(r0 + j) * WG_GS + gcol + 16]; }
+                const u32x4 b0 = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g0[2], g0[3]), pack_bf16x2(g0[4], g0[5]), pack_bf16x2(g0[6], g0[7])};
+                const u32x4 b1 = {pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g1[2], g1[3]), pack_bf16x2(g1[4], g1[5]), pack_bf16x2(g1[6], g1[7])};
+                if (NTAP == 1) {
+                    float av[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = Al[min(r0 + j, RI) * WG_AS + acol];
+                    const u32x4 af = {pack_bf16x2(av[0], av[1]), pack_bf16x2(av[2], av[3]), pack_bf16x2(av[4], av[5]), pack_bf16x2(av[6], av[7])};
+                    acc[0][0] = mfma16_bf16(af, b0, acc[0][0]); acc[0][1] = mfma16_bf16(af, b1, acc[0][1]);
+                } else {
+                    uint32_t w[8][3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { w[j][0] = rt[(r0 + j) * 4]; w[j][1] = rt[(r0 + j) * 4 + 1]; w[j][2] = rt[(r0 + j) * 4 + 2]; }
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) {
+                        float av[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t ww = t < 4 ? w[j][0] : t < 8 ? w[j][1] : w[j][2];
+                            av[j] = Al[(int)((ww >> (8 * (t & 3))) & 255u) * WG_AS + acol];
+                        }
+                        const u32x4 af = {pack_bf16x2(av[0], av[1]), pack_bf16x2(av[2], av[3]), pack_bf16x2(av[4], av[5]), pack_bf16x2(av[6], av[7])};
+                        acc[t][0] = mfma16_bf16(af, b0, acc[t][0]); acc[t][1] = mfma16_bf16(af, b1, acc[t][1]);
+                    }
+                }
+            }
+        } else
         for (int ks = 0; ks < RO4; ks += 4) {
             const int row = ks + kq;
             const float b0 = Gl[row * WG_GS + gcol], b1 = Gl[row * WG_GS + gcol + 16];

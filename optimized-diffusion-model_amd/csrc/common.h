@@ -50,7 +50,25 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
-__device__ __forceinline__ f32x4 mfma16_bf16(u32x4, u32x4, f32x4 c) { abort(); return c; }      // the CPU emulator does not execute bf16 kernels
+#if defined(RDMI_EMU)
+// CPU emulator (tests/emu): the wave's 64 fragments are exchanged and every lane forms its four outputs in fp32
+__device__ __forceinline__ float bf2f_host(bf16_t h) { const unsigned u = (unsigned)h << 16; return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    bf16_t A[64][8], B[64][8];
+    std::memcpy(A, emu::wave_exchange(&a, 16), sizeof A);
+    std::memcpy(B, emu::wave_exchange(&b, 16), sizeof B);
+    const int lane = emu::lane_id(), col = lane & 15;
+    for (int e = 0; e < 4; ++e) {
+        const int r = (lane >> 4) * 4 + e;
+        float s = c[e];
+        for (int k = 0; k < 32; ++k) s += bf2f_host(A[r + 16 * (k >> 3)][k & 7]) * bf2f_host(B[col + 16 * (k >> 3)][k & 7]);
+        c[e] = s;
+    }
+    return c;
+}
+#else
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4, u32x4, f32x4 c) { abort(); return c; }      // host pass of hipcc: never executed
+#endif
 #endif
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 

@@ -56,7 +56,19 @@ int launch_wgrad(WgradArgs w, hipStream_t s) {
     const int tiles = ceil_div(w.Cin, 32) * ceil_div(w.Cout, 64), chunks = ceil_div(w.NB, w.S);
     w.ksplit = std::max(1, std::min(chunks, 512 / tiles));
     const dim3 grid((unsigned)w.ksplit, (unsigned)ceil_div(w.Cin, 32), (unsigned)ceil_div(w.Cout, 64));
-    const size_t lds = wgrad_lds_bytes(w.HWv, w.HWo, w.S);
+    const size_t lds = wgrad_lds_bytes(w.HWv, w.HWo, w.S, w.bf16);
+    if (w.bf16) {
+        static bool attr16 = false;
+        if (!attr16) {
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((wgrad_mfma_kernel<9, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((wgrad_mfma_kernel<1, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr16 = true;
+        }
+        if (w.ntap == 9) hipLaunchKernelGGL((wgrad_mfma_kernel<9, true>), grid, dim3(RDMI_THREADS), lds, s, w);
+        else if (w.ntap == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<1, true>), grid, dim3(RDMI_THREADS), lds, s, w);
+        else return fail("wgrad: %d taps", w.ntap);
+        return 0;
+    }
     if (w.ntap == 9) hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(RDMI_THREADS), lds, s, w);
     else if (w.ntap == 1) hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(RDMI_THREADS), lds, s, w);
     else return fail("wgrad: %d taps", w.ntap);
@@ -408,6 +420,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
             w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
             w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
+            w.bf16 = c->arch.compute_dtype == 1;
             if (int e = launch_wgrad(w, s)) return e;
         }
         // scatter the input gradient to the source tensors
@@ -432,6 +445,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
             w.NB = NB; w.HWv = fa.HWo; w.HWo = fa.HWo; w.Cin = Csc; w.Cout = sp.Cout; w.ntap = 1; w.lda = fa.Csc;
             w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
+            w.bf16 = c->arch.compute_dtype == 1;
             if (int e = launch_wgrad(w, s)) return e;
             const long tot = (long)NB * fa.HWsa * fa.CscA + (long)NB * fa.HWo * fa.CscB;
             hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GS,

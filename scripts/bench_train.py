@@ -1,5 +1,5 @@
-"""Secondary measurement (BASELINE config #4 shape, fp32): score-matching training steps/s at batch 128 on one GPU.
-Not the driver's bench.py; prints one JSON line."""
+"""Secondary measurement (BASELINE config #4 shape): score-matching training steps/s on one GPU.
+usage: bench_train.py [B] [train_dtype f32|bf16].  Not the driver's bench.py; prints one JSON line."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'optimized-diffusion-model_amd'))
@@ -9,7 +9,9 @@ from rdmi import losses, sde_lib
 from rdmi.models.ema import ExponentialMovingAverage
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+DT = sys.argv[2] if len(sys.argv) > 2 else 'f32'
 model, cfg, _ = ge.make_model(dev)
+model.train_dtype = DT
 model.train()
 sde = sde_lib.RVESDE(0.01, 5, N=1000)
 opt = losses.get_optimizer(cfg, model.parameters())
@@ -24,5 +26,5 @@ K = 10
 for _ in range(K):
     l = step_fn(state, batch, class_labels=labels)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-print(json.dumps({'metric': 'score-matching training step (fp32, dropout 0.2, label drop 0.5, Adam+clip+EMA)', 'batch': B,
+print(json.dumps({'metric': 'score-matching training step (dropout 0.2, label drop 0.5, Adam+clip+EMA)', 'train_dtype': DT, 'batch': B,
                   'ms_per_step': dt * 1e3, 'samples_per_s': B / dt, 'loss': float(l.detach())}))

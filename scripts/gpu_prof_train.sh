@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/proft2
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/proft2 -o t -- python3 scripts/bench_train.py ${1:-128} > gpurun_out/proft2/out.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/proft2 -o t -- python3 scripts/bench_train.py ${1:-128} ${2:-f32} > gpurun_out/proft2/out.log 2>&1
 python3 - <<'PY'
 import csv
 rows = list(csv.DictReader(open("gpurun_out/proft2/t_kernel_stats.csv")))
