@@ -17,6 +17,7 @@ struct AttnArgs {
     const float* b3;       // [C]
     int NB, L, Lpad, G;
     float eps, scale, out_scale;
+    int io_bf16;           // x and out are bf16 (training step with train_dtype = bf16)
 };
 
 template <int C>
@@ -46,11 +47,11 @@ __global__ __launch_bounds__(RDMI_THREADS) void attn_mfma_kernel(AttnArgs a) {
     float* stat = P + (size_t)Lpad * PS;                   // [G][2]
 
     // ---- load x (rows >= L zero)
-    const float* xg = a.x + (size_t)n * L * C;
+    const float* xg = a.io_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(a.x) + (size_t)n * L * C) : a.x + (size_t)n * L * C;
     for (int i = tid; i < Lpad * (C / 4); i += RDMI_THREADS) {
         const int p = i / (C / 4), c = (i - p * (C / 4)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p < L) v = *reinterpret_cast<const f32x4*>(xg + (size_t)p * C + c);
+        if (p < L) v = ldact4(xg, (size_t)p * C + c, a.io_bf16);
         *reinterpret_cast<f32x4*>(Xn + (size_t)p * RS + c) = v;
     }
     __syncthreads();
@@ -200,13 +201,13 @@ __global__ __launch_bounds__(RDMI_THREADS) void attn_mfma_kernel(AttnArgs a) {
             }
         }
         const float b = a.b3[col];
-        float* og = a.out + (size_t)n * L * C;
+        float* og = a.io_bf16 ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)n * L * C) : a.out + (size_t)n * L * C;
 #pragma unroll
         for (int i = 0; i < MTMAX; ++i)
             if (i < mtiles)
                 for (int r = 0; r < 4; ++r) {
                     const int row = i * 16 + kq * 4 + r;
-                    if (row < L) og[(size_t)row * C + col] = (xg[(size_t)row * C + col] + acc[i][r] + b) * a.out_scale;
+                    if (row < L) stact1(og, (size_t)row * C + col, (ldact1(xg, (size_t)row * C + col, a.io_bf16) + acc[i][r] + b) * a.out_scale, a.io_bf16);
                 }
     }
 }

@@ -24,7 +24,7 @@
 __global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const float* __restrict__ gY, float* __restrict__ G,
                                                                          float* __restrict__ gR, float scale, float* __restrict__ gdense,
                                                                          int dense_stride, int dense_off, float* __restrict__ db,
-                                                                         float* __restrict__ db2, int HW, int C) {
+                                                                         float* __restrict__ db2, int HW, int C, int g_bf16) {
     __shared__ float red[RDMI_THREADS];
     const int n = blockIdx.x, tid = threadIdx.x;
     for (int c0 = 0; c0 < C; c0 += RDMI_THREADS) {
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const fl
             for (int p = r; p < HW; p += R) {
                 const size_t i = ((size_t)n * HW + p) * C + c;
                 const float g = gY[i] * scale;
-                G[i] = g;
+                stact1(G, i, g, g_bf16);
                 if (gR) gR[i] += g;
                 s += g;
             }
@@ -64,6 +64,7 @@ struct GnBwdArgs {
     const float* gamma; const float* beta; float* dgamma; float* dbeta;
     int G, has_gn; float eps;
     float drop_p; uint64_t seed; uint32_t op_id;
+    int a_bf16, b_bf16, s_bf16;   // element type of srcA, of srcB, and of the scratch tensors GA / ACT (0 fp32, 1 bf16)
 };
 
 __global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
@@ -80,21 +81,20 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (c < a.CA) {
                 const int nA = a.srcA_mod > 0 ? n % a.srcA_mod : n;
-                const float* p = a.srcA + ((size_t)nA * a.HWa + (a.mapA ? a.mapA[v] : v)) * a.CA + c;
-                if ((a.CA & 3) == 0) val = *reinterpret_cast<const f32x4*>(p);
-                else for (int j = 0; j < 4; ++j) if (c + j < a.CA) val[j] = p[j];
+                const size_t ia = ((size_t)nA * a.HWa + (a.mapA ? a.mapA[v] : v)) * a.CA + c;
+                if ((a.CA & 3) == 0) val = ldact4(a.srcA, ia, a.a_bf16);
+                else for (int j = 0; j < 4; ++j) if (c + j < a.CA) val[j] = ldact1(a.srcA, ia + j, a.a_bf16);
             } else if (c < a.CA + a.CB) {
-                val = *reinterpret_cast<const f32x4*>(a.srcB + ((size_t)n * a.HWv + v) * a.CB + (c - a.CA));
+                val = ldact4(a.srcB, ((size_t)n * a.HWv + v) * a.CB + (c - a.CA), a.b_bf16);
             }
             *reinterpret_cast<f32x4*>(V + (size_t)v * rs + c) = val;
-            *reinterpret_cast<f32x4*>(Gt + (size_t)v * rs + c) = *reinterpret_cast<const f32x4*>(a.GA + ((size_t)n * a.HWv + v) * a.Cv + c);
+            *reinterpret_cast<f32x4*>(Gt + (size_t)v * rs + c) = ldact4(a.GA, ((size_t)n * a.HWv + v) * a.Cv + c, a.s_bf16);
         }
     }
     __syncthreads();
-    float* act_out = a.ACT + (size_t)n * a.HWv * a.Cv;
-    float* gv_out = a.GA + (size_t)n * a.HWv * a.Cv;
+    const size_t base = (size_t)n * a.HWv * a.Cv;               // element offset of this sample in ACT / GA
     if (!a.has_gn) {
-        for (int i = tid; i < a.HWv * a.Cv; i += RDMI_THREADS) { const int v = i / a.Cv, c = i - v * a.Cv; act_out[i] = V[(size_t)v * rs + c]; }
+        for (int i = tid; i < a.HWv * a.Cv; i += RDMI_THREADS) { const int v = i / a.Cv, c = i - v * a.Cv; stact1(a.ACT, base + i, V[(size_t)v * rs + c], a.s_bf16); }
         return;                                                   // GV == GA already in place
     }
     const int G = a.G, Cg = a.Cv / G, cnt = Cg * a.HWv;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
             const float y = xh * gm + bt;
             const float sg = 1.0f / (1.0f + __expf(-y));
             const float ds = dropout_scale(a.seed, a.op_id, ((uint64_t)n * a.HWv + v) * a.Cv + c, a.drop_p);
-            act_out[(size_t)v * a.Cv + c] = y * sg * ds;
+            stact1(a.ACT, base + (size_t)v * a.Cv + c, y * sg * ds, a.s_bf16);
             const float gy = Gt[(size_t)v * rs + c] * ds * (sg * (1.0f + y * (1.0f - sg)));
             dg += gy * xh; dbt += gy;
             V[(size_t)v * rs + c] = xh;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
     __syncthreads();
     for (int i = tid; i < a.HWv * a.Cv; i += RDMI_THREADS) {
         const int v = i / a.Cv, c = i - v * a.Cv, g = c / Cg;
-        gv_out[i] = stat[4 * g + 1] * (Gt[(size_t)v * rs + c] - stat[4 * g + 2] - V[(size_t)v * rs + c] * stat[4 * g + 3]);
+        stact1(a.GA, base + i, stat[4 * g + 1] * (Gt[(size_t)v * rs + c] - stat[4 * g + 2] - V[(size_t)v * rs + c] * stat[4 * g + 3]), a.s_bf16);
     }
 }
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
 __global__ __launch_bounds__(RDMI_THREADS) void scatter_grad_kernel(const float* __restrict__ GV, float* __restrict__ gA,
                                                                      float* __restrict__ gB, const int* __restrict__ inv_start,
                                                                      const int* __restrict__ inv_list, int NB, int HWa, int HWv,
-                                                                     int CA, int CB, int Cv) {
+                                                                     int CA, int CB, int Cv, int gv_bf16) {
     const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
     const long nA = (long)NB * HWa * CA, nB = (long)NB * HWv * CB;
     if (i < nA) {
@@ -166,15 +166,15 @@ __global__ __launch_bounds__(RDMI_THREADS) void scatter_grad_kernel(const float*
         const int s = (int)(r % HWa);
         const long n = r / HWa;
         float acc = 0.f;
-        if (inv_start) { for (int k = inv_start[s]; k < inv_start[s + 1]; ++k) acc += GV[((size_t)n * HWv + inv_list[k]) * Cv + c]; }
-        else acc = GV[((size_t)n * HWv + s) * Cv + c];
+        if (inv_start) { for (int k = inv_start[s]; k < inv_start[s + 1]; ++k) acc += ldact1(GV, ((size_t)n * HWv + inv_list[k]) * Cv + c, gv_bf16); }
+        else acc = ldact1(GV, ((size_t)n * HWv + s) * Cv + c, gv_bf16);
         gA[i] += acc;
     } else if (i < nA + nB) {
         if (!gB) return;
         const long j = i - nA;
         const int c = (int)(j % CB);
         const long r = j / CB;                                   // n * HWv + v
-        gB[j] += GV[(size_t)r * Cv + CA + c];
+        gB[j] += ldact1(GV, (size_t)r * Cv + CA + c, gv_bf16);
     }
 }
 
@@ -193,6 +193,7 @@ struct WgradArgs {
     int ksplit;            // number of sample slices
     int S;                 // samples per staged chunk: S*HWv <= 255, S*HWo <= 128
     long s_co, s_ci, s_t;  // strides of dW
+    int s_bf16;            // ACT and G are bf16 in HBM (widened to fp32 as they are staged)
     int bf16;              // 1: v_mfma_f32_16x16x32_bf16 over 32 staged rows per step (operands rounded to bf16 as they leave LDS, fp32 accumulate)
 };
 #define WG_AS 40
@@ -239,24 +240,23 @@ __global__ __launch_bounds__(RDMI_THREADS) void wgrad_mfma_kernel(WgradArgs a) {
     auto fetch = [&](int n0) {
         const int nv = min(S, n_hi - n0);
         const int rows_a = nv * a.HWv, rows_g = nv * a.HWo;
-        const float* Ab = a.ACT + (size_t)n0 * a.HWv * a.lda;
-        const float* Gb = a.G + (size_t)n0 * a.HWo * a.Cout;
+        const size_t Ab = (size_t)n0 * a.HWv * a.lda, Gb = (size_t)n0 * a.HWo * a.Cout;   // element offsets
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = i * RDMI_THREADS + tid, row = e >> 3, c = ci0 + 4 * (e & 7);
             ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < rows_a && c + 3 < a.lda) ra[i] = ldg4(Ab + (size_t)row * a.lda + c);
+            if (row < rows_a && c + 3 < a.lda) ra[i] = a.s_bf16 ? ldact4(a.ACT, Ab + (size_t)row * a.lda + c, 1) : ldg4(a.ACT + Ab + (size_t)row * a.lda + c);
         }
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int e = i * RDMI_THREADS + tid, row = e >> 4, c = co0 + 4 * (e & 15);
             rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row < rows_g) {
-                const float* g = Gb + (size_t)row * a.Cout + c;
-                if (gvec) { if (c + 3 < a.Cout) rg[i] = ldg4(g); }
+                const size_t gi = Gb + (size_t)row * a.Cout + c;
+                if (gvec) { if (c + 3 < a.Cout) rg[i] = a.s_bf16 ? ldact4(a.G, gi, 1) : ldg4(a.G + gi); }
                 else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (c + q < a.Cout) rg[i][q] = ldg1(g + q);
+                    for (int q = 0; q < 4; ++q) if (c + q < a.Cout) rg[i][q] = a.s_bf16 ? ldact1(a.G, gi + q, 1) : ldg1(a.G + gi + q);
                 }
             }
         }
@@ -473,6 +473,7 @@ struct AttnBwdArgs {
     const float* W[4]; const float* b[4];      // NIN_0..3: W [in][out]
     float* dW[4]; float* db[4];
     int NB, L, G; float eps, scale, out_scale;
+    int x_bf16;                                // x is bf16 in HBM (train_dtype = bf16)
 };
 
 template <int C>
@@ -557,10 +558,10 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
     };
 
     for (int n = blockIdx.x; n < a.NB; n += gridDim.x) {
-        const float* xg = a.x + (size_t)n * L * C;
+        const size_t xo = (size_t)n * L * C;
         const float* gog = a.gOut + (size_t)n * L * C;
         // ---- stage x (-> O) and gH (-> GP); GroupNorm statistics; O <- xn
-        for (int p = wave; p < L; p += NW) { O[p * LD + lane] = ldg1(xg + p * C + lane); GP[p * LD + lane] = ldg1(gog + p * C + lane) * a.out_scale; }
+        for (int p = wave; p < L; p += NW) { O[p * LD + lane] = a.x_bf16 ? ldact1(a.x, xo + p * C + lane, 1) : ldg1(a.x + xo + p * C + lane); GP[p * LD + lane] = ldg1(gog + p * C + lane) * a.out_scale; }
         {
             float s1 = 0.f;
             for (int p = wave; p < L; p += NW) s1 += O[p * LD + lane];
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
                      reinterpret_cast<f32x4(&)[3]>(hold[3]));
         {
             const float m = stat[4 * (lane / Cg)], rs = stat[4 * (lane / Cg) + 1];
-            for (int p = wave; p < L; p += NW) P[p * LD + lane] = (ldg1(xg + p * C + lane) - m) * rs;
+            for (int p = wave; p < L; p += NW) P[p * LD + lane] = ((a.x_bf16 ? ldact1(a.x, xo + p * C + lane, 1) : ldg1(a.x + xo + p * C + lane)) - m) * rs;
         }
         __syncthreads();
         store3(Q, reinterpret_cast<f32x4(&)[3]>(hold[0]), 0.f);

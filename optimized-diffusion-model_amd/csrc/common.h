@@ -71,6 +71,22 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4, u32x4, f32x4 c) { abort(); r
 #endif
 #endif
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+// Activation tensors of the training step are fp32 or (train_dtype = bf16) bf16 in HBM: same element indexing, `bf` selects the
+// element width.  Loads widen exactly; stores round to nearest even.  idx must be a multiple of 4 for the 4-wide forms.
+__device__ __forceinline__ f32x4 ldact4(const float* base, size_t idx, int bf) {
+    if (bf) {
+        typedef unsigned int u32x2 __attribute__((vector_size(8)));
+        const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(base) + idx);
+        return f32x4{__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u), __builtin_bit_cast(float, u[1] << 16),
+                     __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+    }
+    return *reinterpret_cast<const f32x4*>(base + idx);
+}
+__device__ __forceinline__ float ldact1(const float* base, size_t idx, int bf) { return bf ? bf2f(reinterpret_cast<const bf16_t*>(base)[idx]) : base[idx]; }
+__device__ __forceinline__ void stact1(float* base, size_t idx, float v, int bf) {
+    if (bf) reinterpret_cast<bf16_t*>(base)[idx] = f2bf(v); else base[idx] = v;
+}
 
 // All-reduce over the 16 lanes of a DPP row (lanes 16r..16r+15) in four VALU-DPP steps (quad_perm xor 1, xor 2,
 // row_half_mirror, row_mirror).  __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round trip of ~100+ cycles per

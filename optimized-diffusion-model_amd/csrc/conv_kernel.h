@@ -60,6 +60,8 @@ struct ConvArgs {
     float drop_p; uint64_t drop_seed; uint32_t op_id;   // train mode: dropout after GN+SiLU (Dropout_0, RD/models/layerspp.py:204)
     int bf16;                     // 1: wpk / wsc are the bf16 copies [tap][C/32][Cout_pad][32] and the MFMAs take bf16 operands (fp32 accumulate);
                                   //    needs Cv % 32 == 0 and Csc % 32 == 0 (training with compute_dtype = bf16, BASELINE config #4)
+    int a_bf16, b_bf16, o_bf16;   // element type of srcA / scA, of srcB / scB / resid, and of out: 0 fp32, 1 bf16 (train_dtype = bf16 keeps the
+                                  // activation workspace and the backward scratch tensors in bf16; the caller's x / out stay fp32)
     int dbg;                      // unused (kept so the argument block layout of recorded launches stays stable)
 };
 
@@ -76,7 +78,7 @@ __host__ __device__ inline size_t conv_lds_bytes(const ConvArgs& a) {
 __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const float* __restrict__ A,
                                            const float* __restrict__ B, const int* __restrict__ map, int CA,
                                            int CB, int Cpad, int HWsrc, int HWdst, int S, int n0, int NB,
-                                           int a_mod, int tid) {
+                                           int a_mod, int tid, int a_bf = 0, int b_bf = 0) {
     const int c4n = Cpad >> 2;
     const int total = S * HWdst * c4n;
     const int dpv = RDMI_THREADS / c4n, dc4 = RDMI_THREADS - dpv * c4n;
@@ -90,15 +92,15 @@ __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const 
         if (n < NB) {
             if (c < CA) {
                 const int nA = a_mod > 0 ? n % a_mod : n;
-                const float* p = A + ((size_t)nA * HWsrc + (map ? map[v] : v)) * CA + c;
+                const size_t ia = ((size_t)nA * HWsrc + (map ? map[v] : v)) * CA + c;
                 if ((CA & 3) == 0) {
-                    val = *reinterpret_cast<const f32x4*>(p);
+                    val = ldact4(A, ia, a_bf);
                 } else {
                     for (int j = 0; j < 4; ++j)
-                        if (c + j < CA) val[j] = p[j];
+                        if (c + j < CA) val[j] = ldact1(A, ia + j, a_bf);
                 }
             } else if (c < CA + CB) {
-                val = *reinterpret_cast<const f32x4*>(B + ((size_t)n * HWdst + v) * CB + (c - CA));
+                val = ldact4(B, ((size_t)n * HWdst + v) * CB + (c - CA), b_bf);
             }
         }
         *reinterpret_cast<f32x4*>(L + (size_t)pv * rs + c) = val;
@@ -326,8 +328,8 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
                     const size_t o = ((size_t)n0 * a.HWo + row) * a.Cout + col;
                     float v = acc[i][t][r] + add;
                     if (a.dense) v += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
-                    if (a.resid) v += a.resid[o];
-                    a.out[o] = v * a.out_scale;
+                    if (a.resid) v += ldact1(a.resid, o, a.b_bf16);
+                    stact1(a.out, o, v * a.out_scale, a.o_bf16);
                 }
             }
         }
@@ -354,9 +356,9 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
     const int tw = a.ntap + 1;
 
     // ---- stage 1: gather inputs, copy the tap table
-    conv_stage(X, rs, a.srcA, a.srcB, a.mapA, a.CA, a.CB, a.Cv, a.HWa, a.HWv, a.S, n0, a.NB, a.srcA_mod, tid);
+    conv_stage(X, rs, a.srcA, a.srcB, a.mapA, a.CA, a.CB, a.Cv, a.HWa, a.HWv, a.S, n0, a.NB, a.srcA_mod, tid, a.a_bf16, a.b_bf16);
     if (a.Csc)
-        conv_stage(XS, rss, a.scA, a.scB, a.mapSc, a.CscA, a.CscB, a.Csc, a.HWsa, a.HWo, a.S, n0, a.NB, a.scA_mod, tid);
+        conv_stage(XS, rss, a.scA, a.scB, a.mapSc, a.CscA, a.CscB, a.Csc, a.HWsa, a.HWo, a.S, n0, a.NB, a.scA_mod, tid, a.a_bf16, a.b_bf16);
     for (int i = tid; i < a.Mpad * tw; i += RDMI_THREADS) tabL[i] = a.tab[i];
 
     // ---- stage 2: GroupNorm statistics (two-pass, in LDS) + affine + SiLU, in place

@@ -468,14 +468,14 @@ __global__ __launch_bounds__(64) void sm_loss_kernel(const float* __restrict__ s
 
 // NHWC -> NCHW copy (debug taps and the C=1 boundary is a no-op)
 __global__ __launch_bounds__(RDMI_THREADS) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                                     int NB, int HW, int C) {
+                                                                     int NB, int HW, int C, int src_bf16) {
     const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
     if (i >= (long)NB * HW * C) return;
     const int c = (int)(i % C);
     const long r = i / C;
     const int p = (int)(r % HW);
     const long n = r / HW;
-    dst[(n * C + c) * HW + p] = src[i];
+    dst[(n * C + c) * HW + p] = ldact1(src, (size_t)i, src_bf16);
 }
 
 // Post-sampling un-normalisation of the GTO-Halo 67-vectors (Benchmark/gto_halo_benchmarking.py:255-333 and

@@ -1807,7 +1807,7 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             hipLaunchKernelGGL(transpose_lc_kernel, dim3((unsigned)((n + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, l.tsrc, l.tdst, NB, l.tL, l.tC, l.tld, l.tc0);
         }
     }
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)c->t_out, out, NB, HW, Cc);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((tot + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)c->t_out, out, NB, HW, Cc, 0);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -2376,7 +2376,7 @@ int rdmi_get_tap(rdmi_ctx* c, const char* name, float* dst, size_t dst_numel, in
             const size_t per = (size_t)a.Cout * a.Ho * a.Wo;
             const int nb = (int)std::min<size_t>(dst_numel / per, (size_t)c->max_batch);
             hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)ceil_div((int)(nb * per), RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)a.out, dst, nb,
-                               a.Ho * a.Wo, a.Cout);
+                               a.Ho * a.Wo, a.Cout, 0);
             HIP_OK(hipGetLastError());
             return 0;
         }
@@ -2394,7 +2394,7 @@ int rdmi_get_tap(rdmi_ctx* c, const char* name, float* dst, size_t dst_numel, in
         const size_t per = t.per_sample();
         const int nb = (int)std::min<size_t>(dst_numel / per, (size_t)c->max_batch);
         hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)ceil_div((int)(nb * per), RDMI_THREADS)), dim3(RDMI_THREADS), 0, s,
-                           (const float*)(c->ws + t.off * (size_t)c->max_batch), dst, nb, t.H * t.W, t.C);
+                           (const float*)(c->ws + t.off * (size_t)c->max_batch), dst, nb, t.H * t.W, t.C, c->arch.compute_dtype == 1 ? 1 : 0);
         HIP_OK(hipGetLastError());
         return 0;
     }

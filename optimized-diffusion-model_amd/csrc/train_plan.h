@@ -133,6 +133,11 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             }
             ca.bf16 = 1;
         }
+        // activation storage: the workspace tensors are bf16 (same element offsets, half the bytes); the caller's x and out stay fp32
+        for (auto& op : c->ops) {
+            if (op.kind == OP_CONV) { op.conv.a_bf16 = op.a_is_input ? 0 : 1; op.conv.b_bf16 = 1; op.conv.o_bf16 = op.out_is_output ? 0 : 1; }
+            else op.attn.io_bf16 = 1;
+        }
         HIP_OK(hipMalloc((void**)&c->d_w16, std::max<size_t>(w16, 64) * sizeof(bf16_t)));
         HIP_OK(hipMemset(c->d_w16, 0, std::max<size_t>(w16, 64) * sizeof(bf16_t)));
         size_t k = 0;
@@ -220,6 +225,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             j.Cin = sp.Cout; j.Cout = Cin; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 9;
             j.s_co = 9; j.s_ci = (long)Cin * 9; j.s_t = 1; j.kind = 0;     // "co" of the job = ci of W, "ci" of the job = co of W
             if (bf && (d.Cv & 31) == 0) { j.kind = 2; d.bf16 = 1; }
+            if (bf) { d.a_bf16 = 1; d.o_bf16 = 1; }
             T.jobs.push_back(j); T.job_param.push_back(b.p_w);
         }
         if (b.has_sc) {
@@ -238,6 +244,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             j.Cin = sp.Cout; j.Cout = Csc; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 1;
             j.s_co = sp.Cout; j.s_ci = 1; j.s_t = 0; j.kind = 0;            // NIN W [in=Csc][out=Cout]: job "co" = in, job "ci" = out
             if (bf && (d.Cv & 31) == 0) { j.kind = 2; d.bf16 = 1; }
+            if (bf) { d.a_bf16 = 1; d.o_bf16 = 1; }
             T.jobs.push_back(j); T.job_param.push_back(b.p_wsc);
         }
         // inverse nearest maps for the scatter of gradients back to mapped sources
@@ -348,6 +355,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
     hipStream_t s = (hipStream_t)stream;
     const int NB = T.last_B;
     const size_t NBmax = (size_t)c->max_batch;
+    const int sbf = c->arch.compute_dtype == 1;      // bf16 activation workspace and scratch tensors
     // transposed packs
     for (size_t i = 0; i < T.jobs.size(); ++i) T.jobs[i].src = c->params[(size_t)T.job_param[i]].ptr;
     if (!T.jobs.empty()) {
@@ -382,7 +390,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
                 const int pw = c->pindex.at(op.name + ".NIN_" + std::to_string(k) + ".W"), pb = c->pindex.at(op.name + ".NIN_" + std::to_string(k) + ".b");
                 a.W[k] = c->params[(size_t)pw].ptr; a.b[k] = c->params[(size_t)pb].ptr; a.dW[k] = pgrad(pw); a.db[k] = pgrad(pb);
             }
-            a.NB = NB; a.L = op.attn.L; a.G = op.attn.G; a.eps = op.attn.eps; a.scale = op.attn.scale; a.out_scale = op.attn.out_scale;
+            a.NB = NB; a.L = op.attn.L; a.G = op.attn.G; a.eps = op.attn.eps; a.scale = op.attn.scale; a.out_scale = op.attn.out_scale; a.x_bf16 = sbf;
             hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3((unsigned)std::min(NB, 256)), dim3(AB_THREADS), attn_bwd_lds_bytes<64>(a.L, a.G), s, a);
             HIP_OK(hipGetLastError());
             continue;
@@ -394,7 +402,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         const float* gY = op.out_is_output ? grad_out : gptr(op.out_tensor);
         // G = scale * gY (+ identity residual) and the bias / NIN-bias / Dense_0 gradients (column sums of G)
         hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, gY, T.G, gptr(op.tRes), fa.out_scale,
-                           op.use_dense ? T.gdense : (float*)nullptr, c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout);
+                           op.use_dense ? T.gdense : (float*)nullptr, c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout, sbf);
         // data gradient w.r.t. the activated input
         if (b.has_dgrad) {
             ConvArgs d = b.dgrad; d.NB = NB;
@@ -405,7 +413,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             GnBwdArgs g{};
             g.srcA = op.a_is_input ? x : fa.srcA; g.srcB = fa.srcB; g.mapA = fa.mapA;
             g.CA = fa.CA; g.CB = fa.CB; g.Cv = fa.Cv; g.HWa = fa.HWa; g.HWv = fa.HWv; g.srcA_mod = 0; g.NB = NB;
-            g.GA = T.GA; g.ACT = T.ACT;
+            g.GA = T.GA; g.ACT = T.ACT; g.a_bf16 = op.a_is_input ? 0 : sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
             g.has_gn = b.has_gn ? 1 : 0; g.G = fa.G; g.eps = fa.eps;
             if (b.has_gn) { g.gamma = fa.gamma; g.beta = fa.beta; g.dgamma = pgrad(b.p_gamma); g.dbeta = pgrad(b.p_beta); }
             g.drop_p = op.dropout ? T.drop_p : 0.f; g.seed = T.seed; g.op_id = (uint32_t)oi;
@@ -420,7 +428,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
             w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
             w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
-            w.bf16 = c->arch.compute_dtype == 1;
+            w.bf16 = sbf; w.s_bf16 = sbf;
             if (int e = launch_wgrad(w, s)) return e;
         }
         // scatter the input gradient to the source tensors
@@ -428,7 +436,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             const long tot = (long)NB * fa.HWa * fa.CA + (long)NB * fa.HWv * fa.CB;
             hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GA,
                                gptr(op.tA), gptr(op.tB), b.has_invA ? T.d_int + b.invA_start : (const int*)nullptr,
-                               b.has_invA ? T.d_int + b.invA_list : (const int*)nullptr, NB, fa.HWa, fa.HWv, fa.CA, fa.CB, fa.Cv);
+                               b.has_invA ? T.d_int + b.invA_list : (const int*)nullptr, NB, fa.HWa, fa.HWv, fa.CA, fa.CB, fa.Cv, sbf);
         }
         // NIN shortcut: data gradient, weight gradient, scatter
         if (b.has_sc) {
@@ -437,7 +445,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             GnBwdArgs g{};
             g.srcA = fa.scA; g.srcB = fa.scB; g.mapA = fa.mapSc;
             g.CA = fa.CscA; g.CB = fa.CscB; g.Cv = fa.Csc; g.HWa = fa.HWsa; g.HWv = fa.HWo; g.NB = NB;
-            g.GA = T.GS; g.ACT = T.ACT; g.has_gn = 0;
+            g.GA = T.GS; g.ACT = T.ACT; g.has_gn = 0; g.a_bf16 = sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
             const size_t lds = ((size_t)2 * (fa.HWo + 1) * (fa.Csc + 4) + 4 * 32) * 4;
             hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), lds, s, g);
             WgradArgs w{};
@@ -445,12 +453,12 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
             w.NB = NB; w.HWv = fa.HWo; w.HWo = fa.HWo; w.Cin = Csc; w.Cout = sp.Cout; w.ntap = 1; w.lda = fa.Csc;
             w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
-            w.bf16 = c->arch.compute_dtype == 1;
+            w.bf16 = sbf; w.s_bf16 = sbf;
             if (int e = launch_wgrad(w, s)) return e;
             const long tot = (long)NB * fa.HWsa * fa.CscA + (long)NB * fa.HWo * fa.CscB;
             hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GS,
                                gptr(op.tScA), gptr(op.tScB), b.has_invS ? T.d_int + b.invS_start : (const int*)nullptr,
-                               b.has_invS ? T.d_int + b.invS_list : (const int*)nullptr, NB, fa.HWsa, fa.HWo, fa.CscA, fa.CscB, fa.Csc);
+                               b.has_invS ? T.d_int + b.invS_list : (const int*)nullptr, NB, fa.HWsa, fa.HWo, fa.CscA, fa.CscB, fa.Csc, sbf);
         }
         HIP_OK(hipGetLastError());
     }
