@@ -52,31 +52,38 @@ __global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const fl
     }
 }
 
-// GroupNorm(+SiLU+dropout) backward for one sample per workgroup, everything in LDS.
+// GroupNorm(+SiLU+dropout) backward for one sample per workgroup (GN_THREADS work-items), everything in LDS, followed by the
+// scatter of the input gradient to the gradient accumulators of the op's sources.
 //   V  : raw virtual input, gathered like the forward (concat of mapped A and B)
-//   GA : gradient w.r.t. the activated tensor  [n][HWv][Cv]   (overwritten by GV = gradient w.r.t. V)
+//   GA : gradient w.r.t. the activated tensor  [n][HWv][Cv]   (read only; GV = gradient w.r.t. V stays in LDS)
 //   ACT: the activated tensor itself is written out for the weight-gradient GEMM
-// has_gn == 0: GV = GA, ACT = V (plain convs: up/down-sampling, input conv).
+//   gA[n][s][c] += sum_{v in inv(s)} GV[v][c] (c < CA),  gB[n][v][c-CA] += GV[v][c] (c >= CA): the workgroup owns its sample's
+//   rows of gA / gB, so these are plain read-modify-writes (inv_start / inv_list: inverse of the nearest map, null = identity).
+// has_gn == 0: GV = GA, ACT = V (plain convs: up/down-sampling, input conv, NIN shortcut).
+#define GN_THREADS 1024
 struct GnBwdArgs {
     const float* srcA; const float* srcB; const int* mapA;
     int CA, CB, Cv, HWa, HWv, srcA_mod, NB;
-    float* GA; float* ACT;
+    const float* GA; float* ACT;
     const float* gamma; const float* beta; float* dgamma; float* dbeta;
     int G, has_gn; float eps;
     float drop_p; uint64_t seed; uint32_t op_id;
     int a_bf16, b_bf16, s_bf16;   // element type of srcA, of srcB, and of the scratch tensors GA / ACT (0 fp32, 1 bf16)
+    float* gA; float* gB; const int* inv_start; const int* inv_list;   // fp32 gradient accumulators (null: that source takes no gradient)
 };
+__host__ __device__ inline size_t gn_bwd_lds_bytes(int HWv, int Cv) { return ((size_t)2 * (HWv + 1) * (Cv + 4) + 4 * 32 + 2 * GN_THREADS) * 4; }
 
-__global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
     const int tid = threadIdx.x, n = blockIdx.x;
     const int rs = a.Cv + 4;
-    float* V = reinterpret_cast<float*>(rdmi_lds);               // [HWv][rs]
-    float* Gt = V + (size_t)(a.HWv + 1) * rs;                     // [HWv][rs]  gy / gxhat
+    float* V = reinterpret_cast<float*>(rdmi_lds);               // [HWv + 1][rs]
+    float* Gt = V + (size_t)(a.HWv + 1) * rs;                     // [HWv][rs]  gy / gxhat / GV
     float* stat = Gt + (size_t)a.HWv * rs;                        // [G][4]: mean, rstd, m1, m2
-    // gather V (reuses the forward staging code: S = 1)
+    float* red = stat + 4 * 32;                                   // [2][GN_THREADS] partial dgamma / dbeta
+    // gather V (same addressing as the forward staging with S = 1) and the incoming gradient
     {
         const int c4n = a.Cv >> 2, total = a.HWv * c4n;
-        for (int i = tid; i < total; i += RDMI_THREADS) {
+        for (int i = tid; i < total; i += GN_THREADS) {
             const int v = i / c4n, c = (i - v * c4n) << 2;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (c < a.CA) {
@@ -94,60 +101,86 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
     __syncthreads();
     const size_t base = (size_t)n * a.HWv * a.Cv;               // element offset of this sample in ACT / GA
     if (!a.has_gn) {
-        for (int i = tid; i < a.HWv * a.Cv; i += RDMI_THREADS) { const int v = i / a.Cv, c = i - v * a.Cv; stact1(a.ACT, base + i, V[(size_t)v * rs + c], a.s_bf16); }
-        return;                                                   // GV == GA already in place
-    }
-    const int G = a.G, Cg = a.Cv / G, cnt = Cg * a.HWv;
-    // group statistics (two-pass), one group per work-item subset: T lanes per group
-    {
-        const int T = RDMI_THREADS / G;                           // G in {16, 32} -> T in {16, 8}
-        const int g = tid / T, sub = tid - g * T;
-        float s = 0.f;
-        for (int e = sub; e < cnt; e += T) { const int v = e / Cg, cc = e - v * Cg; s += V[(size_t)v * rs + g * Cg + cc]; }
-        for (int m = T >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        const float mean = s / (float)cnt;
-        float q = 0.f;
-        for (int e = sub; e < cnt; e += T) { const int v = e / Cg, cc = e - v * Cg; const float d = V[(size_t)v * rs + g * Cg + cc] - mean; q += d * d; }
-        for (int m = T >> 1; m >= 1; m >>= 1) q += __shfl_xor(q, m);
-        if (sub == 0) { stat[4 * g] = mean; stat[4 * g + 1] = 1.0f / sqrtf(q / (float)cnt + a.eps); }
-    }
-    __syncthreads();
-    // per element: xhat, y, activation (+dropout), gy; V <- xhat, Gt <- gxhat = gy * gamma; channel sums for dgamma/dbeta
-    for (int c = tid; c < a.Cv; c += RDMI_THREADS) {
-        const int g = c / Cg;
-        const float mean = stat[4 * g], rstd = stat[4 * g + 1], gm = a.gamma[c], bt = a.beta[c];
-        float dg = 0.f, dbt = 0.f;
-        for (int v = 0; v < a.HWv; ++v) {
-            const float xh = (V[(size_t)v * rs + c] - mean) * rstd;
-            const float y = xh * gm + bt;
-            const float sg = 1.0f / (1.0f + __expf(-y));
-            const float ds = dropout_scale(a.seed, a.op_id, ((uint64_t)n * a.HWv + v) * a.Cv + c, a.drop_p);
-            stact1(a.ACT, base + (size_t)v * a.Cv + c, y * sg * ds, a.s_bf16);
-            const float gy = Gt[(size_t)v * rs + c] * ds * (sg * (1.0f + y * (1.0f - sg)));
-            dg += gy * xh; dbt += gy;
-            V[(size_t)v * rs + c] = xh;
-            Gt[(size_t)v * rs + c] = gy * gm;
+        for (int i = tid; i < a.HWv * a.Cv; i += GN_THREADS) { const int v = i / a.Cv, c = i - v * a.Cv; stact1(a.ACT, base + i, V[(size_t)v * rs + c], a.s_bf16); }
+    } else {
+        const int G = a.G, Cg = a.Cv / G, cnt = Cg * a.HWv;
+        const int T = min(64, GN_THREADS / G);                    // G in {16, 32} -> T in {64, 32} lanes per group (inside one wave)
+        const int g = tid / T, sub = tid - g * T;                 // waves with g >= G sit the group phases out
+        // group statistics (two-pass)
+        if (g < G) {
+            float s = 0.f;
+            for (int e = sub; e < cnt; e += T) { const int v = e / Cg, cc = e - v * Cg; s += V[(size_t)v * rs + g * Cg + cc]; }
+            for (int m = T >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+            const float mean = s / (float)cnt;
+            float q = 0.f;
+            for (int e = sub; e < cnt; e += T) { const int v = e / Cg, cc = e - v * Cg; const float d = V[(size_t)v * rs + g * Cg + cc] - mean; q += d * d; }
+            for (int m = T >> 1; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+            if (sub == 0) { stat[4 * g] = mean; stat[4 * g + 1] = 1.0f / sqrtf(q / (float)cnt + a.eps); }
         }
-        atomicAdd(a.dgamma + c, dg);
-        atomicAdd(a.dbeta + c, dbt);
-    }
-    __syncthreads();
-    {
-        const int T = RDMI_THREADS / G;
-        const int g = tid / T, sub = tid - g * T;
-        float m1 = 0.f, m2 = 0.f;
-        for (int e = sub; e < cnt; e += T) {
-            const int v = e / Cg, cc = e - v * Cg;
-            const float gx = Gt[(size_t)v * rs + g * Cg + cc];
-            m1 += gx; m2 += gx * V[(size_t)v * rs + g * Cg + cc];
+        __syncthreads();
+        // per element: xhat, y, activation (+dropout), gy; V <- xhat, Gt <- gxhat = gy * gamma; channel sums for dgamma / dbeta.
+        // Work-item (r, c) walks the rows r, r + R, ... of channel c.
+        {
+            const int R = GN_THREADS / a.Cv, r = tid / a.Cv, c = tid - r * a.Cv;
+            float dg = 0.f, dbt = 0.f;
+            if (r < R) {
+                const int gg = c / Cg;
+                const float mean = stat[4 * gg], rstd = stat[4 * gg + 1], gm = a.gamma[c], bt = a.beta[c];
+                for (int v = r; v < a.HWv; v += R) {
+                    const float xh = (V[(size_t)v * rs + c] - mean) * rstd;
+                    const float y = xh * gm + bt;
+                    const float sg = 1.0f / (1.0f + __expf(-y));
+                    const float ds = dropout_scale(a.seed, a.op_id, ((uint64_t)n * a.HWv + v) * a.Cv + c, a.drop_p);
+                    stact1(a.ACT, base + (size_t)v * a.Cv + c, y * sg * ds, a.s_bf16);
+                    const float gy = Gt[(size_t)v * rs + c] * ds * (sg * (1.0f + y * (1.0f - sg)));
+                    dg += gy * xh; dbt += gy;
+                    V[(size_t)v * rs + c] = xh;
+                    Gt[(size_t)v * rs + c] = gy * gm;
+                }
+            }
+            red[tid] = dg; red[GN_THREADS + tid] = dbt;
+            __syncthreads();
+            if (tid < a.Cv) {
+                float sg2 = 0.f, sb2 = 0.f;
+                for (int j = 0; j < R; ++j) { sg2 += red[j * a.Cv + tid]; sb2 += red[GN_THREADS + j * a.Cv + tid]; }
+                atomicAdd(a.dgamma + tid, sg2);
+                atomicAdd(a.dbeta + tid, sb2);
+            }
         }
-        for (int m = T >> 1; m >= 1; m >>= 1) { m1 += __shfl_xor(m1, m); m2 += __shfl_xor(m2, m); }
-        if (sub == 0) { stat[4 * g + 2] = m1 / (float)cnt; stat[4 * g + 3] = m2 / (float)cnt; }
+        if (g < G) {
+            float m1 = 0.f, m2 = 0.f;
+            for (int e = sub; e < cnt; e += T) {
+                const int v = e / Cg, cc = e - v * Cg;
+                const float gx = Gt[(size_t)v * rs + g * Cg + cc];
+                m1 += gx; m2 += gx * V[(size_t)v * rs + g * Cg + cc];
+            }
+            for (int m = T >> 1; m >= 1; m >>= 1) { m1 += __shfl_xor(m1, m); m2 += __shfl_xor(m2, m); }
+            if (sub == 0) { stat[4 * g + 2] = m1 / (float)cnt; stat[4 * g + 3] = m2 / (float)cnt; }
+        }
+        __syncthreads();
+        for (int i = tid; i < a.HWv * a.Cv; i += GN_THREADS) {
+            const int v = i / a.Cv, c = i - v * a.Cv, gg = c / Cg;
+            Gt[(size_t)v * rs + c] = stat[4 * gg + 1] * (Gt[(size_t)v * rs + c] - stat[4 * gg + 2] - V[(size_t)v * rs + c] * stat[4 * gg + 3]);
+        }
     }
     __syncthreads();
-    for (int i = tid; i < a.HWv * a.Cv; i += RDMI_THREADS) {
-        const int v = i / a.Cv, c = i - v * a.Cv, g = c / Cg;
-        stact1(a.GA, base + i, stat[4 * g + 1] * (Gt[(size_t)v * rs + c] - stat[4 * g + 2] - V[(size_t)v * rs + c] * stat[4 * g + 3]), a.s_bf16);
+    // scatter GV (in Gt) to the sources' gradient accumulators
+    if (a.gA) {
+        float* ga = a.gA + (size_t)n * a.HWa * a.CA;
+        for (int i = tid; i < a.HWa * a.CA; i += GN_THREADS) {
+            const int sp = i / a.CA, c = i - sp * a.CA;
+            float acc = 0.f;
+            if (a.inv_start) { for (int k = a.inv_start[sp]; k < a.inv_start[sp + 1]; ++k) acc += Gt[(size_t)a.inv_list[k] * rs + c]; }
+            else acc = Gt[(size_t)sp * rs + c];
+            ga[i] += acc;
+        }
+    }
+    if (a.gB) {
+        float* gb = a.gB + (size_t)n * a.HWv * a.CB;
+        for (int i = tid; i < a.HWv * a.CB; i += GN_THREADS) {
+            const int v = i / a.CB, c = i - v * a.CB;
+            gb[i] += Gt[(size_t)v * rs + a.CA + c];
+        }
     }
 }
 
@@ -372,12 +405,14 @@ struct SgemmArgs {
 };
 // C[M][N] (+)= act(A)[M][K] * act(B)[K][N], any strides.  64x64 output tile per workgroup (4 waves x 2x2 MFMA tiles),
 // K split over blockIdx.z (atomics when split or accumulating; the caller zeroes C first in that case).
-__global__ __launch_bounds__(RDMI_THREADS) void small_gemm_kernel(SgemmArgs a) {
+__device__ __forceinline__ void small_gemm_body(const SgemmArgs& a, int kz, int nkz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
+    if ((int)blockIdx.x * 64 >= a.M || (int)blockIdx.y * 64 >= a.N) return;
     const int m0 = blockIdx.x * 64 + (wave >> 1) * 32, n0 = blockIdx.y * 64 + (wave & 1) * 32;
-    const int kc = (a.K + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int kb = blockIdx.z * kc, ke = min(a.K, kb + kc);
+    const int kc = (a.K + nkz - 1) / nkz;
+    const int kb = kz * kc, ke = min(a.K, kb + kc);
+    if (kb >= ke) return;
     f32x4 acc[2][2] = {};
     long ao[2], bo[2];
     bool av[2], bv[2];
@@ -410,7 +445,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void small_gemm_kernel(SgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(x[i], y[j], acc[i][j]);
     }
-    const bool atomic = a.accumulate || gridDim.z > 1;
+    const bool atomic = a.accumulate || nkz > 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -424,6 +459,16 @@ __global__ __launch_bounds__(RDMI_THREADS) void small_gemm_kernel(SgemmArgs a) {
                     else *c = acc[i][j][r];
                 }
             }
+}
+
+__global__ __launch_bounds__(RDMI_THREADS) void small_gemm_kernel(SgemmArgs a) { small_gemm_body(a, blockIdx.z, gridDim.z); }
+// Several independent small GEMMs in one launch: blockIdx.z = job * ks + K slice (a no_split job uses slice 0 only);
+// grid x / y cover the largest job, surplus workgroups of the smaller ones exit at once.
+__global__ __launch_bounds__(RDMI_THREADS) void small_gemm_jobs_kernel(const SgemmArgs* __restrict__ jobs, int ks) {
+    const int j = blockIdx.z / ks, kz = blockIdx.z - j * ks;
+    const SgemmArgs a = jobs[j];
+    if (a.no_split) { if (kz == 0) small_gemm_body(a, 0, 1); }
+    else small_gemm_body(a, kz, ks);
 }
 
 // g <- g * silu'(x)
@@ -448,6 +493,23 @@ __global__ __launch_bounds__(RDMI_THREADS) void colsum2d_kernel(const float* __r
     red[threadIdx.x] = s;
     __syncthreads();
     if (r == 0 && c < C) atomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// Batched column sums: job j adds the column sums of X_j [M][C_j] (row stride ldx) to out_j.  grid (max C / 64, row slabs, jobs).
+struct ColsumJob { const float* X; float* out; int C; int pad; };
+__global__ __launch_bounds__(RDMI_THREADS) void colsum_jobs_kernel(const ColsumJob* __restrict__ jobs, int M, int ldx) {
+    __shared__ float red[RDMI_THREADS];
+    const ColsumJob jb = jobs[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= jb.C) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+    const int per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int mb = blockIdx.y * per, me = min(M, mb + per);
+    float s = 0.f;
+    if (c < jb.C)
+        for (int m = mb + r; m < me; m += 4) s += jb.X[(size_t)m * ldx + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (r == 0 && c < jb.C) atomicAdd(jb.out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // Fourier features of log(sigma) materialised for the time_mlp.0 weight gradient: F[m][0:nf] = sin, [nf:2nf] = cos

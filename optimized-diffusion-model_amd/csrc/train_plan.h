@@ -29,6 +29,9 @@ struct TrainPlan {
     std::vector<size_t> poff;            // flat-gradient offset of every parameter
     size_t ptotal = 0;
     float drop_p = 0.f; uint64_t seed = 0; int last_B = 0; int label_rows = 0;
+    SgemmArgs* d_gemm_jobs = nullptr; ColsumJob* d_col_jobs = nullptr;   // job tables of the embedding backward (64 entries each)
+    std::vector<SgemmArgs> h_gemm_jobs; std::vector<ColsumJob> h_col_jobs;
+    std::vector<SgemmArgs> m_gemm_jobs; std::vector<ColsumJob> m_col_jobs;   // host mirror of what the device tables hold (uploads only on change)
 };
 
 void conv_tile_cfg(ConvArgs& a, int& cfg) {
@@ -280,6 +283,9 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     HIP_OK(hipMalloc((void**)&T.gta, Mp * c->temb * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.gh1, Mp * c->temb * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.four, Mp * 2 * c->arch.nf * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&T.d_gemm_jobs, 64 * sizeof(SgemmArgs)));
+    HIP_OK(hipMalloc((void**)&T.d_col_jobs, 64 * sizeof(ColsumJob)));
+    T.h_gemm_jobs.reserve(64); T.h_col_jobs.reserve(64);
     HIP_OK(hipMalloc((void**)&T.sig_copy, Mp * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.lab_copy, Mp * std::max(1, c->arch.num_classes) * sizeof(float)));
     // resolve pointers of the data-gradient convs
@@ -417,9 +423,13 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.has_gn = b.has_gn ? 1 : 0; g.G = fa.G; g.eps = fa.eps;
             if (b.has_gn) { g.gamma = fa.gamma; g.beta = fa.beta; g.dgamma = pgrad(b.p_gamma); g.dbeta = pgrad(b.p_beta); }
             g.drop_p = op.dropout ? T.drop_p : 0.f; g.seed = T.seed; g.op_id = (uint32_t)oi;
-            const size_t lds = ((size_t)2 * (fa.HWv + 1) * (fa.Cv + 4) + 4 * 32) * 4;
+            if (b.has_dgrad) {
+                g.gA = gptr(op.tA); g.gB = gptr(op.tB);
+                if (b.has_invA) { g.inv_start = T.d_int + b.invA_start; g.inv_list = T.d_int + b.invA_list; }
+            }
+            const size_t lds = gn_bwd_lds_bytes(fa.HWv, fa.Cv);
             if (lds > 160 * 1024) return fail("gn backward of %s: LDS %zu B", sp.name.c_str(), lds);
-            hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), lds, s, g);
+            hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(GN_THREADS), lds, s, g);
         }
         // weight gradient (reference OIHW layout): dW[co][ci][t] += sum ACT[in(o,t)][ci] G[o][co]
         {
@@ -431,13 +441,6 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.bf16 = sbf; w.s_bf16 = sbf;
             if (int e = launch_wgrad(w, s)) return e;
         }
-        // scatter the input gradient to the source tensors
-        if (b.has_dgrad) {
-            const long tot = (long)NB * fa.HWa * fa.CA + (long)NB * fa.HWv * fa.CB;
-            hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GA,
-                               gptr(op.tA), gptr(op.tB), b.has_invA ? T.d_int + b.invA_start : (const int*)nullptr,
-                               b.has_invA ? T.d_int + b.invA_list : (const int*)nullptr, NB, fa.HWa, fa.HWv, fa.CA, fa.CB, fa.Cv, sbf);
-        }
         // NIN shortcut: data gradient, weight gradient, scatter
         if (b.has_sc) {
             ConvArgs d = b.scgrad; d.NB = NB;
@@ -446,8 +449,9 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.srcA = fa.scA; g.srcB = fa.scB; g.mapA = fa.mapSc;
             g.CA = fa.CscA; g.CB = fa.CscB; g.Cv = fa.Csc; g.HWa = fa.HWsa; g.HWv = fa.HWo; g.NB = NB;
             g.GA = T.GS; g.ACT = T.ACT; g.has_gn = 0; g.a_bf16 = sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
-            const size_t lds = ((size_t)2 * (fa.HWo + 1) * (fa.Csc + 4) + 4 * 32) * 4;
-            hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), lds, s, g);
+            g.gA = gptr(op.tScA); g.gB = gptr(op.tScB);
+            if (b.has_invS) { g.inv_start = T.d_int + b.invS_start; g.inv_list = T.d_int + b.invS_list; }
+            hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(GN_THREADS), gn_bwd_lds_bytes(fa.HWo, fa.Csc), s, g);
             WgradArgs w{};
             const int Csc = sp.CscA + sp.CscB;
             w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
@@ -455,39 +459,72 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
             w.bf16 = sbf; w.s_bf16 = sbf;
             if (int e = launch_wgrad(w, s)) return e;
-            const long tot = (long)NB * fa.HWsa * fa.CscA + (long)NB * fa.HWo * fa.CscB;
-            hipLaunchKernelGGL(scatter_grad_kernel, dim3((unsigned)ceil_div((int)tot, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, (const float*)T.GS,
-                               gptr(op.tScA), gptr(op.tScB), b.has_invS ? T.d_int + b.invS_start : (const int*)nullptr,
-                               b.has_invS ? T.d_int + b.invS_list : (const int*)nullptr, NB, fa.HWsa, fa.HWo, fa.CscA, fa.CscB, fa.Csc, sbf);
         }
         HIP_OK(hipGetLastError());
     }
 
-    // ---- embedding backward: Dense_0 (x17) -> SiLU -> [label_emb, time_mlp.2] -> SiLU -> time_mlp.0
+    // ---- embedding backward: Dense_0 (x17) -> SiLU -> [label_emb, time_mlp.2] -> SiLU -> time_mlp.0.  Independent GEMMs and
+    //      bias column sums of one stage go out as one job-table launch each (tables staged in T.h_*: they live until the next call).
     const int Tm = c->temb, DT = c->dense_total, nf = c->arch.nf;
     {
+        auto& GJ = T.h_gemm_jobs; auto& CJ = T.h_col_jobs;
+        GJ.clear(); CJ.clear();
+        size_t g_used = 0, c_used = 0;                         // entries of the device tables already consumed by earlier launches
+        T.m_gemm_jobs.resize(64); T.m_col_jobs.resize(64);
+        auto flush_gemm = [&]() -> int {
+            const size_t nj = GJ.size() - g_used;
+            if (!nj) return 0;
+            if (GJ.size() > 64) return fail("embedding backward: %zu GEMM jobs", GJ.size());
+            int mm = 0, mn = 0, mk = 0;
+            for (size_t i = g_used; i < GJ.size(); ++i) { mm = std::max(mm, GJ[i].M); mn = std::max(mn, GJ[i].N); if (!GJ[i].no_split) mk = std::max(mk, GJ[i].K); }
+            const int ks = std::max(1, std::min(ceil_div(std::max(mk, 1), 64), 16));
+            if (std::memcmp(T.m_gemm_jobs.data() + g_used, GJ.data() + g_used, nj * sizeof(SgemmArgs)) != 0) {   // same buffers as last step: already resident
+                std::memcpy(T.m_gemm_jobs.data() + g_used, GJ.data() + g_used, nj * sizeof(SgemmArgs));
+                HIP_OK(hipMemcpyAsync(T.d_gemm_jobs + g_used, GJ.data() + g_used, nj * sizeof(SgemmArgs), hipMemcpyHostToDevice, s));
+            }
+            hipLaunchKernelGGL(small_gemm_jobs_kernel, dim3((unsigned)ceil_div(mm, 64), (unsigned)ceil_div(mn, 64), (unsigned)(nj * ks)), dim3(RDMI_THREADS), 0, s,
+                               (const SgemmArgs*)(T.d_gemm_jobs + g_used), ks);
+            g_used = GJ.size();
+            return 0;
+        };
+        auto flush_col = [&](int M, int ldx) -> int {
+            const size_t nj = CJ.size() - c_used;
+            if (!nj) return 0;
+            if (CJ.size() > 64) return fail("embedding backward: %zu column-sum jobs", CJ.size());
+            int mc = 0;
+            for (size_t i = c_used; i < CJ.size(); ++i) mc = std::max(mc, CJ[i].C);
+            if (std::memcmp(T.m_col_jobs.data() + c_used, CJ.data() + c_used, nj * sizeof(ColsumJob)) != 0) {
+                std::memcpy(T.m_col_jobs.data() + c_used, CJ.data() + c_used, nj * sizeof(ColsumJob));
+                HIP_OK(hipMemcpyAsync(T.d_col_jobs + c_used, CJ.data() + c_used, nj * sizeof(ColsumJob), hipMemcpyHostToDevice, s));
+            }
+            hipLaunchKernelGGL(colsum_jobs_kernel, dim3((unsigned)ceil_div(mc, 64), (unsigned)std::max(1, std::min(64, M / 64)), (unsigned)nj), dim3(RDMI_THREADS), 0, s,
+                               (const ColsumJob*)(T.d_col_jobs + c_used), M, ldx);
+            c_used = CJ.size();
+            return 0;
+        };
         Layout L = build_layout(c);
         std::vector<std::pair<std::string, int>> blocks;
         for (auto& d : L.down) blocks.push_back({d.name, d.cout});
         blocks.push_back({"mid_block1", L.mid_ch}); blocks.push_back({"mid_block2", L.mid_ch});
         for (auto& u : L.up) blocks.push_back({u.name, u.cout});
+        HIP_OK(hipMemsetAsync(T.gta, 0, (size_t)pad16(c->max_batch) * Tm * sizeof(float), s));
         int off = 0;
-        bool first = true;
         for (auto& bl : blocks) {
             const int pw = c->pindex.at(bl.first + ".Dense_0.weight"), pb = c->pindex.at(bl.first + ".Dense_0.bias");
             SgemmArgs g{};   // dWd[co][k] = sum_n gdense[n][off+co] * silu(temb[n][k])
             g.A = T.gdense + off; g.a_m = 1; g.a_k = DT; g.a_act = 0;
             g.B = c->d_temb; g.b_k = Tm; g.b_n = 1; g.b_act = 1;
             g.C = pgrad(pw); g.c_m = Tm; g.c_n = 1; g.accumulate = 0; g.M = bl.second; g.N = Tm; g.K = NB;
-            if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(bl.second, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)(T.gdense + off), pgrad(pb), NB, bl.second, DT);
-            SgemmArgs h{};   // gta[n][k] (+)= sum_co gdense[n][off+co] * Wd[co][k]
+            GJ.push_back(g);
+            CJ.push_back(ColsumJob{T.gdense + off, pgrad(pb), bl.second, 0});
+            SgemmArgs h{};   // gta[n][k] += sum_co gdense[n][off+co] * Wd[co][k]   (gta zeroed above; the 17 blocks add with atomics)
             h.A = T.gdense + off; h.a_m = DT; h.a_k = 1; h.B = c->params[(size_t)pw].ptr; h.b_k = Tm; h.b_n = 1;
-            h.C = T.gta; h.c_m = Tm; h.c_n = 1; h.accumulate = first ? 0 : 1; h.M = NB; h.N = Tm; h.K = bl.second; h.no_split = 1;
-            if (int e = launch_small_gemm(h, s)) return e;
-            first = false;
+            h.C = T.gta; h.c_m = Tm; h.c_n = 1; h.accumulate = 1; h.M = NB; h.N = Tm; h.K = bl.second; h.no_split = 1;
+            GJ.push_back(h);
             off += bl.second;
         }
+        if (int e = flush_gemm()) return e;
+        if (int e = flush_col(NB, DT)) return e;
         hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)ceil_div(NB * Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, T.gta, (const float*)c->d_temb, (long)NB * Tm);
         // gta is now g(temb)
         if (c->arch.conditional) {
@@ -495,20 +532,22 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             SgemmArgs g{};   // dWl[k][cl] = sum_n gtemb[n][k] * labels[n][cl]
             g.A = T.gta; g.a_m = 1; g.a_k = Tm; g.B = T.lab_copy; g.b_k = nc; g.b_n = 1; g.C = pgrad(pw); g.c_m = nc; g.c_n = 1;
             g.M = Tm; g.N = nc; g.K = NB;
-            if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
+            GJ.push_back(g);
+            CJ.push_back(ColsumJob{T.gta, pgrad(pb), Tm, 0});
         }
         {
             const int pw = c->pindex.at("time_mlp.2.weight"), pb = c->pindex.at("time_mlp.2.bias");
             SgemmArgs g{};   // dW2[k][j] = sum_n gtemb[n][k] * silu(h1[n][j])
             g.A = T.gta; g.a_m = 1; g.a_k = Tm; g.B = c->d_h1; g.b_k = Tm; g.b_n = 1; g.b_act = 1; g.C = pgrad(pw); g.c_m = Tm; g.c_n = 1;
             g.M = Tm; g.N = Tm; g.K = NB;
-            if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)T.gta, pgrad(pb), NB, Tm, Tm);
+            GJ.push_back(g);
+            CJ.push_back(ColsumJob{T.gta, pgrad(pb), Tm, 0});
             SgemmArgs h{};   // gh1[n][j] = sum_k gtemb[n][k] * W2[k][j]
             h.A = T.gta; h.a_m = Tm; h.a_k = 1; h.B = c->params[(size_t)pw].ptr; h.b_k = Tm; h.b_n = 1; h.C = T.gh1; h.c_m = Tm; h.c_n = 1;
             h.M = NB; h.N = Tm; h.K = Tm; h.no_split = 1;
-            if (int e = launch_small_gemm(h, s)) return e;
+            GJ.push_back(h);
+            if (int e = flush_gemm()) return e;
+            if (int e = flush_col(NB, Tm)) return e;
             hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)ceil_div(NB * Tm, RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, T.gh1, (const float*)c->d_h1, (long)NB * Tm);
         }
         {
@@ -518,8 +557,10 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             SgemmArgs g{};   // dW0[j][f] = sum_n gh1[n][j] * four[n][f]
             g.A = T.gh1; g.a_m = 1; g.a_k = Tm; g.B = T.four; g.b_k = 2 * nf; g.b_n = 1; g.C = pgrad(pw); g.c_m = 2 * nf; g.c_n = 1;
             g.M = Tm; g.N = 2 * nf; g.K = NB;
-            if (int e = launch_small_gemm(g, s)) return e;
-            hipLaunchKernelGGL(colsum2d_kernel, dim3((unsigned)ceil_div(Tm, 64), (unsigned)std::max(1, std::min(64, NB / 64))), dim3(RDMI_THREADS), 0, s, (const float*)T.gh1, pgrad(pb), NB, Tm, Tm);
+            GJ.push_back(g);
+            CJ.push_back(ColsumJob{T.gh1, pgrad(pb), Tm, 0});
+            if (int e = flush_gemm()) return e;
+            if (int e = flush_col(NB, Tm)) return e;
         }
         HIP_OK(hipGetLastError());
     }
