@@ -1886,8 +1886,14 @@ int rdmi_create(const rdmi_arch* arch, int max_batch, int H, int W, rdmi_ctx** o
 int rdmi_destroy(rdmi_ctx* c) {
     if (!c) return 0;
     if (TrainPlan* T = get_train(c)) {
-        for (void* p : {(void*)T->d_jobs, (void*)T->d_wb, (void*)T->d_int, (void*)T->gws, (void*)T->G, (void*)T->GA, (void*)T->GS, (void*)T->ACT, (void*)T->zero_bias,
-                        (void*)T->gdense, (void*)T->gta, (void*)T->gh1, (void*)T->four, (void*)T->sig_copy, (void*)T->lab_copy}) if (p) (void)hipFree(p);
+        if (T->side) { (void)hipStreamSynchronize(T->side); (void)hipStreamDestroy(T->side); }
+        for (int p = 0; p < TrainPlan::MAXSETS; ++p) for (void* q : {(void*)T->G[p], (void*)T->ACT[p], (void*)T->ACTS[p]}) if (q) (void)hipFree(q);
+        for (int p = 0; p < 2; ++p) {
+            if (T->ev_ready[p]) (void)hipEventDestroy(T->ev_ready[p]);
+            if (T->ev_done[p]) (void)hipEventDestroy(T->ev_done[p]);
+        }
+        for (void* p : {(void*)T->d_jobs, (void*)T->d_wb, (void*)T->d_int, (void*)T->gws, (void*)T->GA, (void*)T->GS, (void*)T->zero_bias, (void*)T->gdense, (void*)T->gta, (void*)T->gh1, (void*)T->four, (void*)T->sig_copy, (void*)T->lab_copy,
+                        (void*)T->d_gemm_jobs, (void*)T->d_col_jobs}) if (p) (void)hipFree(p);
         train_registry().erase(c);
         delete T;
     }

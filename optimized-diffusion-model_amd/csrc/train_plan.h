@@ -24,7 +24,14 @@ struct TrainPlan {
     float* d_wb = nullptr; size_t wb_floats = 0;       // transposed weight packs
     int* d_int = nullptr;
     float* gws = nullptr;                // gradients of the activation tensors (same offsets as ws)
-    float *G = nullptr, *GA = nullptr, *GS = nullptr, *ACT = nullptr, *zero_bias = nullptr;
+    // scratch of the conv backward.  G / ACT / ACTS exist 2 * group times: the weight-gradient GEMMs of a group of ops run on the
+    // side stream while the main stream already produces the next group's G / ACT into the other half (two event pairs per group).
+    static constexpr int MAXSETS = 16;
+    int group = 8;                       // conv ops per group (RDMI_TRAIN_GROUP), sets = 2 * group
+    float *G[MAXSETS] = {}, *ACT[MAXSETS] = {}, *ACTS[MAXSETS] = {};
+    float *GA = nullptr, *GS = nullptr, *zero_bias = nullptr;
+    hipStream_t side = nullptr; hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool two_streams = true;             // RDMI_TRAIN_STREAMS=1 keeps everything on the caller's stream
     float *gdense = nullptr, *gta = nullptr, *gh1 = nullptr, *four = nullptr, *sig_copy = nullptr, *lab_copy = nullptr;
     std::vector<size_t> poff;            // flat-gradient offset of every parameter
     size_t ptotal = 0;
@@ -272,9 +279,20 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     HIP_OK(hipMemcpy(T.d_int, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc((void**)&T.d_jobs, std::max<size_t>(T.jobs.size(), 1) * sizeof(PackJob)));
     for (auto& j : T.jobs) j.dst = T.d_wb + reinterpret_cast<size_t>(j.dst);
-    HIP_OK(hipMalloc((void**)&T.G, maxG * NBmax * sizeof(float)));
+    if (const char* e = getenv("RDMI_TRAIN_STREAMS")) T.two_streams = atoi(e) != 1;
+    if (const char* e = getenv("RDMI_TRAIN_GROUP")) T.group = std::max(1, std::min(TrainPlan::MAXSETS / 2, atoi(e)));
+    if (!T.two_streams) T.group = 1;
+    for (int p = 0; p < 2 * T.group; ++p) {
+        HIP_OK(hipMalloc((void**)&T.G[p], maxG * NBmax * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.ACT[p], maxV * NBmax * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.ACTS[p], maxS * NBmax * sizeof(float)));
+    }
+    for (int p = 0; p < 2; ++p) {
+        HIP_OK(hipEventCreateWithFlags(&T.ev_ready[p], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&T.ev_done[p], hipEventDisableTiming));
+    }
+    if (T.two_streams) HIP_OK(hipStreamCreateWithFlags(&T.side, hipStreamNonBlocking));
     HIP_OK(hipMalloc((void**)&T.GA, maxV * NBmax * sizeof(float)));
-    HIP_OK(hipMalloc((void**)&T.ACT, maxV * NBmax * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.GS, maxS * NBmax * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.zero_bias, 1024 * sizeof(float)));
     HIP_OK(hipMemset(T.zero_bias, 0, 1024 * sizeof(float)));
@@ -292,11 +310,11 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     for (auto& b : T.convs) {
         if (b.has_dgrad) {
             ConvArgs& d = b.dgrad;
-            d.srcA = T.G; d.tab = T.d_int + b.tab_off; d.wpk = T.d_wb + b.wT_off; d.bias = T.zero_bias; d.out = T.GA;
+            d.srcA = nullptr; d.tab = T.d_int + b.tab_off; d.wpk = T.d_wb + b.wT_off; d.bias = T.zero_bias; d.out = T.GA;   // srcA = G[parity] at launch
         }
         if (b.has_sc) {
             ConvArgs& d = b.scgrad;
-            d.srcA = T.G; d.tab = T.d_int + b.sctab_off; d.wpk = T.d_wb + b.wscT_off; d.bias = T.zero_bias; d.out = T.GS;
+            d.srcA = nullptr; d.tab = T.d_int + b.sctab_off; d.wpk = T.d_wb + b.wscT_off; d.bias = T.zero_bias; d.out = T.GS;
         }
     }
     T.ready = true;
@@ -385,6 +403,18 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
     std::map<int, const BwdConv*> bmap;
     for (auto& b : T.convs) bmap[b.op] = &b;
 
+    hipStream_t s2 = T.two_streams ? T.side : s;           // weight-gradient stream
+    bool done_rec[2] = {false, false};
+    int nconv = 0;                                          // conv ops seen: set = nconv % (2 * group), group half = set / group
+    std::vector<WgradArgs> pending;                         // weight gradients of the current group
+    auto flush_wgrads = [&](int half) -> int {
+        if (pending.empty()) return 0;
+        if (T.two_streams) { HIP_OK(hipEventRecord(T.ev_ready[half], s)); HIP_OK(hipStreamWaitEvent(s2, T.ev_ready[half], 0)); }
+        for (auto& w : pending) if (int e = launch_wgrad(w, s2)) return e;
+        if (T.two_streams) { HIP_OK(hipEventRecord(T.ev_done[half], s2)); done_rec[half] = true; }
+        pending.clear();
+        return 0;
+    };
     for (int oi = (int)c->ops.size() - 1; oi >= 0; --oi) {
         const Op& op = c->ops[(size_t)oi];
         if (op.kind == OP_ATTN) {
@@ -406,12 +436,16 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         const ConvArgs& fa = op.conv;
         const int Cin = sp.CA + sp.CB;
         const float* gY = op.out_is_output ? grad_out : gptr(op.out_tensor);
+        const int p = nconv % (2 * T.group), half = p / T.group;
+        ++nconv;
+        float* Gp = T.G[p]; float* ACTp = T.ACT[p]; float* ACTSp = T.ACTS[p];
+        if (T.two_streams && p % T.group == 0 && done_rec[half]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[half], 0));   // the group before last has left this half
         // G = scale * gY (+ identity residual) and the bias / NIN-bias / Dense_0 gradients (column sums of G)
-        hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, gY, T.G, gptr(op.tRes), fa.out_scale,
+        hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, gY, Gp, gptr(op.tRes), fa.out_scale,
                            op.use_dense ? T.gdense : (float*)nullptr, c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout, sbf);
         // data gradient w.r.t. the activated input
         if (b.has_dgrad) {
-            ConvArgs d = b.dgrad; d.NB = NB;
+            ConvArgs d = b.dgrad; d.NB = NB; d.srcA = Gp;
             if (int e = launch_conv(b.dgrad_cfg, d, s)) return e;
         }
         // GroupNorm / SiLU / dropout backward (+ materialise ACT for the weight gradient)
@@ -419,7 +453,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             GnBwdArgs g{};
             g.srcA = op.a_is_input ? x : fa.srcA; g.srcB = fa.srcB; g.mapA = fa.mapA;
             g.CA = fa.CA; g.CB = fa.CB; g.Cv = fa.Cv; g.HWa = fa.HWa; g.HWv = fa.HWv; g.srcA_mod = 0; g.NB = NB;
-            g.GA = T.GA; g.ACT = T.ACT; g.a_bf16 = op.a_is_input ? 0 : sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
+            g.GA = T.GA; g.ACT = ACTp; g.a_bf16 = op.a_is_input ? 0 : sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
             g.has_gn = b.has_gn ? 1 : 0; g.G = fa.G; g.eps = fa.eps;
             if (b.has_gn) { g.gamma = fa.gamma; g.beta = fa.beta; g.dgamma = pgrad(b.p_gamma); g.dbeta = pgrad(b.p_beta); }
             g.drop_p = op.dropout ? T.drop_p : 0.f; g.seed = T.seed; g.op_id = (uint32_t)oi;
@@ -431,37 +465,41 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             if (lds > 160 * 1024) return fail("gn backward of %s: LDS %zu B", sp.name.c_str(), lds);
             hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(GN_THREADS), lds, s, g);
         }
-        // weight gradient (reference OIHW layout): dW[co][ci][t] += sum ACT[in(o,t)][ci] G[o][co]
-        {
-            WgradArgs w{};
-            w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_w); w.tab = T.d_int + b.wtab_off;
-            w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
-            w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
-            w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
-            w.bf16 = sbf; w.s_bf16 = sbf;
-            if (int e = launch_wgrad(w, s)) return e;
-        }
-        // NIN shortcut: data gradient, weight gradient, scatter
+        // NIN shortcut: data gradient and its scatter (ACTS = the shortcut's input, for its weight gradient)
         if (b.has_sc) {
-            ConvArgs d = b.scgrad; d.NB = NB;
+            ConvArgs d = b.scgrad; d.NB = NB; d.srcA = Gp;
             if (int e = launch_conv(b.sc_cfg, d, s)) return e;
             GnBwdArgs g{};
             g.srcA = fa.scA; g.srcB = fa.scB; g.mapA = fa.mapSc;
             g.CA = fa.CscA; g.CB = fa.CscB; g.Cv = fa.Csc; g.HWa = fa.HWsa; g.HWv = fa.HWo; g.NB = NB;
-            g.GA = T.GS; g.ACT = T.ACT; g.has_gn = 0; g.a_bf16 = sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
+            g.GA = T.GS; g.ACT = ACTSp; g.has_gn = 0; g.a_bf16 = sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
             g.gA = gptr(op.tScA); g.gB = gptr(op.tScB);
             if (b.has_invS) { g.inv_start = T.d_int + b.invS_start; g.inv_list = T.d_int + b.invS_list; }
             hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(GN_THREADS), gn_bwd_lds_bytes(fa.HWo, fa.Csc), s, g);
+        }
+        // weight gradients on the side stream (reference OIHW layout): dW[co][ci][t] += sum ACT[in(o,t)][ci] G[o][co];  NIN: dWn += Vs^T G
+        {
+            WgradArgs w{};
+            w.ACT = ACTp; w.G = Gp; w.dW = pgrad(b.p_w); w.tab = T.d_int + b.wtab_off;
+            w.NB = NB; w.HWv = fa.HWv; w.HWo = fa.HWo; w.Cin = Cin; w.Cout = sp.Cout; w.ntap = 9;
+            w.lda = fa.Cv;                                   // ACT has Cv (padded) channels per pixel; only ci < Cin are real
+            w.s_co = (long)Cin * 9; w.s_ci = 9; w.s_t = 1;
+            w.bf16 = sbf; w.s_bf16 = sbf;
+            pending.push_back(w);
+        }
+        if (b.has_sc) {
             WgradArgs w{};
             const int Csc = sp.CscA + sp.CscB;
-            w.ACT = T.ACT; w.G = T.G; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
+            w.ACT = ACTSp; w.G = Gp; w.dW = pgrad(b.p_wsc); w.tab = nullptr;
             w.NB = NB; w.HWv = fa.HWo; w.HWo = fa.HWo; w.Cin = Csc; w.Cout = sp.Cout; w.ntap = 1; w.lda = fa.Csc;
             w.s_co = 1; w.s_ci = sp.Cout; w.s_t = 0;                    // NIN W [in][out]
             w.bf16 = sbf; w.s_bf16 = sbf;
-            if (int e = launch_wgrad(w, s)) return e;
+            pending.push_back(w);
         }
+        if (p % T.group == T.group - 1) { if (int e = flush_wgrads(half)) return e; }
         HIP_OK(hipGetLastError());
     }
+    if (int e = flush_wgrads(((nconv - 1) % (2 * T.group)) / T.group)) return e;
 
     // ---- embedding backward: Dense_0 (x17) -> SiLU -> [label_emb, time_mlp.2] -> SiLU -> time_mlp.0.  Independent GEMMs and
     //      bias column sums of one stage go out as one job-table launch each (tables staged in T.h_*: they live until the next call).
@@ -564,6 +602,8 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         }
         HIP_OK(hipGetLastError());
     }
+    if (T.two_streams)                                      // join: the caller's stream continues after the last weight gradients
+        for (int p = 0; p < 2; ++p) if (done_rec[p]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[p], 0));
     return 0;
 }
 
