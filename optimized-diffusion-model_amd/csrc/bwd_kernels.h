@@ -11,7 +11,7 @@
 //                GA = dgrad(G)         (conv_mfma_kernel, adjoint table, W^T)        GS = G . Wn^T (1x1, same kernel)
 //                GV, Act, dgamma, dbeta = gn_bwd(V, GA)                               (gn_bwd_kernel)
 //                dW += Act^T (*) G     (wgrad_mfma_kernel)                            dWn += Vs^T G
-//                gA, gB += scatter(GV [+ GS])                                         (scatter_grad_kernel)
+//                gA, gB += scatter(GV [+ GS])                                         (tail of gn_bwd_kernel)
 #pragma once
 #include "common.h"
 #include "misc_kernels.h"
@@ -181,33 +181,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
             const int v = i / a.CB, c = i - v * a.CB;
             gb[i] += Gt[(size_t)v * rs + a.CA + c];
         }
-    }
-}
-
-// gA[n][s][c] += sum_{v in inv(s)} GV[n][v][c]  (c < CA)   and   gB[n][v][c-CA] += GV[n][v][c]  (c >= CA)
-// inv_start/inv_list: inverse of the nearest map (null = identity).  One work-item per destination element.
-__global__ __launch_bounds__(RDMI_THREADS) void scatter_grad_kernel(const float* __restrict__ GV, float* __restrict__ gA,
-                                                                     float* __restrict__ gB, const int* __restrict__ inv_start,
-                                                                     const int* __restrict__ inv_list, int NB, int HWa, int HWv,
-                                                                     int CA, int CB, int Cv, int gv_bf16) {
-    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
-    const long nA = (long)NB * HWa * CA, nB = (long)NB * HWv * CB;
-    if (i < nA) {
-        if (!gA) return;
-        const int c = (int)(i % CA);
-        const long r = i / CA;
-        const int s = (int)(r % HWa);
-        const long n = r / HWa;
-        float acc = 0.f;
-        if (inv_start) { for (int k = inv_start[s]; k < inv_start[s + 1]; ++k) acc += ldact1(GV, ((size_t)n * HWv + inv_list[k]) * Cv + c, gv_bf16); }
-        else acc = ldact1(GV, ((size_t)n * HWv + s) * Cv + c, gv_bf16);
-        gA[i] += acc;
-    } else if (i < nA + nB) {
-        if (!gB) return;
-        const long j = i - nA;
-        const int c = (int)(j % CB);
-        const long r = j / CB;                                   // n * HWv + v
-        gB[j] += ldact1(GV, (size_t)r * Cv + CA + c, gv_bf16);
     }
 }
 
@@ -461,7 +434,6 @@ __device__ __forceinline__ void small_gemm_body(const SgemmArgs& a, int kz, int 
             }
 }
 
-__global__ __launch_bounds__(RDMI_THREADS) void small_gemm_kernel(SgemmArgs a) { small_gemm_body(a, blockIdx.z, gridDim.z); }
 // Several independent small GEMMs in one launch: blockIdx.z = job * ks + K slice (a no_split job uses slice 0 only);
 // grid x / y cover the largest job, surplus workgroups of the smaller ones exit at once.
 __global__ __launch_bounds__(RDMI_THREADS) void small_gemm_jobs_kernel(const SgemmArgs* __restrict__ jobs, int ks) {
@@ -477,22 +449,6 @@ __global__ __launch_bounds__(RDMI_THREADS) void silu_bwd_kernel(float* __restric
     if (i >= n) return;
     const float y = x[i], sg = 1.0f / (1.0f + __expf(-y));
     g[i] *= sg * (1.0f + y * (1.0f - sg));
-}
-
-// out[c] (+)= sum_m X[m][c]    (bias gradients of the embedding layers)
-__global__ __launch_bounds__(RDMI_THREADS) void colsum2d_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int C,
-                                                                 int ldx) {
-    // grid (C/64, row slabs): 4 row lanes x 64 columns per workgroup, LDS reduce, one atomic per column and slab
-    __shared__ float red[RDMI_THREADS];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-    const int per = (M + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int mb = blockIdx.y * per, me = min(M, mb + per);
-    float s = 0.f;
-    if (c < C)
-        for (int m = mb + r; m < me; m += 4) s += X[(size_t)m * ldx + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (r == 0 && c < C) atomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // Batched column sums: job j adds the column sums of X_j [M][C_j] (row stride ldx) to out_j.  grid (max C / 64, row slabs, jobs).

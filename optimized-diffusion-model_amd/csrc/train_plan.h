@@ -85,16 +85,6 @@ int launch_wgrad(WgradArgs w, hipStream_t s) {
     return 0;
 }
 
-int launch_small_gemm(const SgemmArgs& g, hipStream_t s) {
-    // weight-gradient shapes contract over the batch: split K so that ~1024 workgroups are in flight
-    const int tiles = ceil_div(g.M, 64) * ceil_div(g.N, 64);
-    int ks = 1;
-    if (!g.no_split) ks = std::max(1, std::min(ceil_div(g.K, 64), 1024 / tiles));
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)ceil_div(g.M, 64), (unsigned)ceil_div(g.N, 64), (unsigned)ks), dim3(RDMI_THREADS), 0, s, g);
-    HIP_OK(hipGetLastError());
-    return 0;
-}
-
 int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     const size_t NBmax = (size_t)c->max_batch;
     // ---- every activation keeps its own storage (no liveness reuse) + a gradient twin

@@ -121,7 +121,7 @@ def test_cube_helpers(emu, golden):
     assert np.array_equal(cube.reflect(T(g['reflect_known_in'])).numpy(), g['reflect_known_out'])
     assert np.array_equal(cube.reflect(T(g['reflect_rand_in'])).numpy(), g['reflect_rand_out'])
     hk = cube.score_hk(T(g['hk_x']), T(g['hk_x0']), T(g['hk_sigma'])).numpy()
-    np.testing.assert_allclose(hk, g['hk_score'], rtol=2e-4, atol=1e-3)
+    np.testing.assert_allclose(hk, g['hk_score'], rtol=2e-5, atol=1e-4)
     assert bool(cube.inside(torch.rand(3, 1, 9, 9)).all())
 
 

@@ -60,7 +60,8 @@ def test_score_hk(env, golden):
     g = golden('cube_sde.npz')
     dev = env['dev']
     out = cube.score_hk(T(g['hk_x'], dev), T(g['hk_x0'], dev), T(g['hk_sigma'], dev)).cpu().numpy()
-    np.testing.assert_allclose(out, g['hk_score'], rtol=2e-4, atol=1e-3)
+    # measured on MI355X (scripts/gpu_hk_err.py): max |err| 6.1e-5 at |score| 15.9, max relative error 3.8e-6 where |score| > 0.25
+    np.testing.assert_allclose(out, g['hk_score'], rtol=2e-5, atol=1e-4)
 
 
 def test_forward_9x9_golden(env, golden):

@@ -25,7 +25,7 @@ def test_score_hk(golden):
     t = g['hk_sigma'] ** 2 / 2
     close(O.score_hk_ef(g['hk_x'], g['hk_x0'], t), g['hk_ef_only'], rtol=2e-4, atol=1e-4)
     close(O.score_hk_refl(g['hk_x'], g['hk_x0'], t), g['hk_refl_only'], rtol=2e-4, atol=1e-3)
-    close(O.score_hk(g['hk_x'], g['hk_x0'], g['hk_sigma']), g['hk_score'], rtol=2e-4, atol=1e-3)
+    close(O.score_hk(g['hk_x'], g['hk_x0'], g['hk_sigma']), g['hk_score'], rtol=2e-5, atol=1e-4)   # measured: 3.1e-5 abs, 2.1e-6 rel
 
 
 def test_sde_schedule(golden):
