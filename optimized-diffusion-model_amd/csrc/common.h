@@ -70,6 +70,15 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16_bf16(u32x4, u32x4, f32x4 c) { abort(); return c; }      // host pass of hipcc: never executed
 #endif
 #endif
+// compiler fences (no instructions): sched_fence keeps the machine scheduler from moving code across it; opaque_sgpr makes a
+// wave-uniform value opaque to the optimiser so that addresses derived from it are recomputed where used instead of hoisted
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void opaque_sgpr(int& v) { asm volatile("" : "+s"(v)); }
+#else
+__device__ __forceinline__ void sched_fence() {}
+__device__ __forceinline__ void opaque_sgpr(int&) {}
+#endif
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 // Activation tensors of the training step are fp32 or (train_dtype = bf16) bf16 in HBM: same element indexing, `bf` selects the

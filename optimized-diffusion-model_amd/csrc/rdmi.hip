@@ -162,9 +162,11 @@ struct rdmi_ctx {
     };
     // tiled plan (shapes whose samples do not fit one workgroup: csrc/tiled_kernels.h)
     struct TLaunch {
-        int kind = 0;                 // 0 conv, 1 GroupNorm statistics (pass over the tensor), 2 batched GEMM, 3 softmax, 4 transpose, 5 statistics from channel sums
+        int kind = 0;                 // 0 conv, 1 GroupNorm statistics (pass over the tensor), 2 batched GEMM, 3 softmax, 4 transpose, 5 statistics from channel sums,
+                                      // 6 GroupNorm(+SiLU) written once as bf16 for a pre-activated conv (bf16 plan)
         std::string name;
-        TConvArgs conv{}; int nmt = 4;
+        TConvArgs conv{}; int nmt = 4; bool pre = false;          // pre: input is the bf16 tensor a kind-6 launch wrote (tconv_pre_kernel)
+        GnActArgs gact{};                                                                                       // kind 6
         const float *sA = nullptr, *sB = nullptr; int CA = 0, CB = 0, HW = 0, G = 0; float* stats = nullptr;     // kind 1
         BgemmArgs gemm{};                                                                                       // kind 2
         float* sm = nullptr; long rows_per_sample = 0; int L = 0;                                               // kind 3
@@ -552,13 +554,31 @@ struct TiledBuilder {
     // conv over concat(A, B) [optionally GroupNorm(+SiLU)'d with `st`], 3x3 (stride 1 pad 1 | stride 2 Downsample | nearest x2 Upsample) or 1x1
     TT conv(const std::string& name, const TT& A, const TT* B, const TT* st, const std::string& gn, bool act, int ntap, int stride, bool up,
             size_t w_off, int cout, const std::string& bias_param, size_t bias_arena, int dense_off, const TT* resid, float scale, bool final_out) {
+        // bf16 plan: a 3x3 stride-1 conv behind a GroupNorm reads a tensor that was normalised, activated and rounded to bf16 ONCE
+        // (kind 6) instead of redoing that arithmetic for every staged window element (RDMI_NO_PREACT=1: the one-kernel form)
+        const bool pre = bf16() && st && ntap == 9 && stride == 1 && !up && !final_out && cout % 16 == 0 && A.C % 4 == 0 && (!B || B->C % 4 == 0) &&
+                         (A.C + (B ? B->C : 0)) % 64 == 0 &&
+                         std::getenv("RDMI_NO_PREACT") == nullptr;
+        size_t act_off = 0;
+        if (pre) {
+            const int Cin = A.C + (B ? B->C : 0), Cvp = pad32(Cin);
+            TT actT = talloc((Cvp + 1) / 2, A.H, A.W);               // bf16 [HW][Cv]
+            act_off = actT.off;
+            rdmi_ctx::TLaunch g; g.kind = 6; g.name = name + ".act";
+            g.oA = A.off; g.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; g.oStats = st->off; g.oOut = actT.off;
+            g.gact.CA = A.C; g.gact.CB = B ? B->C : 0; g.gact.Cv = Cvp; g.gact.HW = A.H * A.W;
+            g.gact.G = std::min(Cin / 4, 32); g.gact.Cg = Cin / g.gact.G; g.gact.act = act ? 1 : 0;
+            g.p_gamma = gn + ".weight"; g.p_beta = gn + ".bias";
+            c->tl.push_back(g);
+        }
         TConvArgs a{};
         a.CA = A.C; a.CB = B ? B->C : 0; a.Cv = pad32(a.CA + a.CB);
+        if (pre) { a.CA = a.Cv; a.CB = 0; }
         a.Ha = A.H; a.Wa = A.W; a.up = up ? 1 : 0; a.Hv = up ? 2 * A.H : A.H; a.Wv = up ? 2 * A.W : A.W;
         a.stride = stride; a.ntap = ntap; a.pad_lo = (ntap == 9 && stride == 1) ? 1 : 0;
         a.Ho = stride == 2 ? (a.Hv + 1 - 3) / 2 + 1 : a.Hv; a.Wo = stride == 2 ? (a.Wv + 1 - 3) / 2 + 1 : a.Wv;
         a.TR = a.Wo >= 64 ? 1 : std::max(1, std::min(a.Ho, 64 / a.Wo));
-        if (st) { a.G = std::min((a.CA + a.CB) / 4, 32); a.Cg = (a.CA + a.CB) / a.G; a.act = act ? 1 : 0; }
+        if (st && !pre) { a.G = std::min((a.CA + a.CB) / 4, 32); a.Cg = (a.CA + a.CB) / a.G; a.act = act ? 1 : 0; }
         a.dense_off = dense_off < 0 ? 0 : dense_off; a.dense_stride = c->dense_total;
         a.out_scale = scale;
         a.Cout = cout; a.Cout_pad = pad16(cout);
@@ -572,13 +592,14 @@ struct TiledBuilder {
         rdmi_ctx::TLaunch l; l.kind = 0; l.name = name; l.conv = a;
         l.oC = cs_off;
         l.oA = A.off; l.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; l.oStats = st ? st->off : rdmi_ctx::TLaunch::NONE;
+        if (pre) { l.pre = true; l.oA = act_off; l.oB = rdmi_ctx::TLaunch::NONE; l.oStats = rdmi_ctx::TLaunch::NONE; }
         l.oResid = resid ? resid->off : rdmi_ctx::TLaunch::NONE; l.oOut = out.off;
         l.nmt = (a.TR * a.Wo > 16) ? 4 : 1;
         l.w_off = w_off; l.p_bias = bias_param; l.bias_arena = bias_arena;
-        if (st) { l.p_gamma = gn + ".weight"; l.p_beta = gn + ".bias"; }
+        if (st && !pre) { l.p_gamma = gn + ".weight"; l.p_beta = gn + ".bias"; }
         l.out_is_final = final_out;
         l.use_dense = dense_off >= 0;
-        l.flops_per_sample = 2.0 * a.Ho * a.Wo * cout * (double)ntap * (a.CA + a.CB);
+        l.flops_per_sample = 2.0 * a.Ho * a.Wo * cout * (double)ntap * (A.C + (B ? B->C : 0));
         c->tl.push_back(l);
         return out;
     }
@@ -711,6 +732,7 @@ int finish_tiled_plan(rdmi_ctx* c) {
             a.wpk = c->d_w + l.w_off;
             a.dense = l.use_dense ? c->d_dense : nullptr;
             a.chsum = tl_ptr(c, l.oC);
+            if (l.pre && tconv_pre_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_pre_lds_bytes(a));
             if (tconv_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_lds_bytes(a));
             if (tconv_trv(a) * tconv_wl(a) * 8 > TC_MAXS * RDMI_THREADS) return fail("tiled conv %s: window of %d pixels exceeds the register staging (%d float4 per work-item)", l.name.c_str(), tconv_trv(a) * tconv_wl(a), TC_MAXS);
         } else if (l.kind == 1) {
@@ -721,6 +743,9 @@ int finish_tiled_plan(rdmi_ctx* c) {
             l.sm = tl_ptr(c, l.oA);
         } else if (l.kind == 5) {
             l.sA = tl_ptr(c, l.oA); l.sB = tl_ptr(c, l.oB); l.stats = tl_ptr(c, l.oStats);
+        } else if (l.kind == 6) {
+            l.gact.A = tl_ptr(c, l.oA); l.gact.B = tl_ptr(c, l.oB); l.gact.stats = tl_ptr(c, l.oStats);
+            l.gact.out = reinterpret_cast<bf16_t*>(tl_ptr(c, l.oOut));
         } else {
             l.tsrc = tl_ptr(c, l.oA); l.tdst = tl_ptr(c, l.oOut);
         }
@@ -1627,6 +1652,7 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
         }
     }
     for (auto& l : c->tl) {
+        if (l.kind == 6) { l.gact.gamma = P(c, l.p_gamma); l.gact.beta = P(c, l.p_beta); continue; }
         if (l.kind != 0) continue;
         l.conv.bias = l.p_bias.empty() ? c->d_w + l.bias_arena : P(c, l.p_bias);
         l.conv.gamma = l.p_gamma.empty() ? nullptr : P(c, l.p_gamma);
@@ -1777,8 +1803,15 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
                 if (ca.Cout_pad >= 64 * cand && (long)tiles * NB * ceil_div(ca.Cout_pad, 64 * cand) >= 512) { nct = cand; break; }
             dim3 grid(tiles * (unsigned)NB, (unsigned)ceil_div(ca.Cout_pad, 64 * nct));
             const bool h = a.compute_dtype == 1;
-            const size_t lds = h ? tconv_bf16_lds_bytes(ca) : tconv_lds_bytes(ca);
-            ProfScope ps(c, s, h ? "tconv_kernel<bf16>" : "tconv_kernel<fp32>", l.flops_per_sample * NB);
+            const size_t lds = l.pre ? tconv_pre_lds_bytes(ca) : h ? tconv_bf16_lds_bytes(ca) : tconv_lds_bytes(ca);
+            ProfScope ps(c, s, l.pre ? "tconv_pre_kernel<bf16>" : h ? "tconv_kernel<bf16>" : "tconv_kernel<fp32>", l.flops_per_sample * NB);
+#define RDMI_TCONV_PRE(NMT_, NCT_) hipLaunchKernelGGL((tconv_pre_kernel<NMT_, NCT_>), grid, dim3(RDMI_THREADS), lds, s, ca)
+            if (l.pre) {
+                if (l.nmt == 4) { if (nct == 4) RDMI_TCONV_PRE(4, 4); else if (nct == 2) RDMI_TCONV_PRE(4, 2); else RDMI_TCONV_PRE(4, 1); }
+                else { if (nct == 4) RDMI_TCONV_PRE(1, 4); else if (nct == 2) RDMI_TCONV_PRE(1, 2); else RDMI_TCONV_PRE(1, 1); }
+                continue;
+            }
+#undef RDMI_TCONV_PRE
 #define RDMI_TCONV(NMT_, NCT_)                                                                                                        \
     do {                                                                                                                              \
         if (h) hipLaunchKernelGGL((tconv_kernel<NMT_, NCT_, true>), grid, dim3(RDMI_THREADS), lds, s, ca);                            \
@@ -1794,6 +1827,11 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             ProfScope ps(c, s, a.compute_dtype == 1 ? "bgemm_nt_bf16_kernel" : "bgemm_nt_kernel", l.flops_per_sample * NB);
             if (a.compute_dtype == 1) hipLaunchKernelGGL(bgemm_nt_bf16_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
             else hipLaunchKernelGGL(bgemm_nt_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
+        } else if (l.kind == 6) {
+            GnActArgs g = l.gact; g.NB = NB;
+            const long units = (long)NB * g.HW * (g.Cv / 8);
+            ProfScope ps(c, s, "gn_act_kernel", 0);
+            hipLaunchKernelGGL(gn_act_kernel, dim3((unsigned)((units + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, g);
         } else if (l.kind == 5) {
             ProfScope ps(c, s, "gn_finalize_kernel", 0);
             hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NB), dim3(64), 0, s, l.sA, l.sB, l.CA, l.CB, l.tL, l.tC, l.HW, l.G, 1e-6f, l.stats);

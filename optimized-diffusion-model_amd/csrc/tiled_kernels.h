@@ -128,6 +128,49 @@ __device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g
     }
 }
 
+// Shared epilogue of the tiled convs: bias, Dense_0(temb) column add, residual, 1/sqrt2 (and 1/sigma), store, per-tile channel sums.
+template <int NMT, int NCT>
+__device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, const f32x4 (&acc)[NMT][NCT], int n, int tile, int tiles_per_img, int oy0, int col0, int kq) {
+    float sdiv = 1.f;
+    if (a.sig) {
+        const float sv = a.sig[a.sig_mod > 0 ? n % a.sig_mod : n];
+        sdiv = a.sig_is_time ? a.smin * powf(a.ratio, sv) : sv;
+    }
+    const float scale = a.out_scale / sdiv;
+    const int HWo = a.Ho * a.Wo, tile_px = a.TR * a.Wo;
+#pragma unroll
+    for (int cc = 0; cc < NCT; ++cc) {
+        const int col = col0 + cc * 16;
+        if (col >= a.Cout) continue;
+        float add = a.bias ? a.bias[col] : 0.f;
+        if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i * 16 + kq * 4 + r;
+                const int opix = oy0 * a.Wo + m;
+                if (m < tile_px && opix < HWo) {
+                    const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
+                    float v = acc[i][cc][r] + add;
+                    if (a.resid) v += a.resid[o];
+                    v *= scale;
+                    a.out[o] = v;
+                    s1 += v; s2 += v * v;
+                }
+            }
+        if (a.chsum) {            // this lane's column over its rows, then over the four k-groups that hold the other rows of the tile
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (kq == 0) {        // every (sample, tile, column) has exactly one writer: no atomics, run-to-run identical
+                float* cs = a.chsum + (((size_t)n * tiles_per_img + tile) * a.Cout + col) * 2;
+                cs[0] = s1; cs[1] = s2;
+            }
+        }
+    }
+}
+
 template <int NMT, int NCT, bool BF16>
 __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,45 +244,152 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
         }
         __syncthreads();
     }
-    // ---- epilogue
-    float sdiv = 1.f;
-    if (a.sig) {
-        const float sv = a.sig[a.sig_mod > 0 ? n % a.sig_mod : n];
-        sdiv = a.sig_is_time ? a.smin * powf(a.ratio, sv) : sv;
-    }
-    const float scale = a.out_scale / sdiv;
-    const int HWo = a.Ho * a.Wo, tile_px = a.TR * a.Wo;
+    tconv_epilogue<NMT, NCT>(a, acc, n, tile, tiles_per_img, oy0, col0, kq);
+}
+
+// ---- bf16 plan, pre-activated inputs -------------------------------------------------------------------------------------------
+// PMC passes over the bf16 plan (profiles/r02_pmc_cifar_b64_bf16.txt) showed tconv_kernel<.., true> issuing ~12 VALU instructions
+// per MFMA: GroupNorm + SiLU + bf16 conversion are redone for every staged window element -- 2.1x the tensor at 32x32 (halo rows)
+// and once more per column-tile workgroup.  For the 3x3 stride-1 convs behind a GroupNorm the plan therefore writes the activated
+// tensor ONCE as bf16 (gn_act_kernel, a streaming pass) and tconv_pre_kernel stages plain 16-byte copies of it.
+struct GnActArgs {
+    const float* A; const float* B;         // concat(A [n][HW][CA], B [n][HW][CB]) fp32; B may be null; CA, CB multiples of 4
+    int CA, CB, Cv, HW, Cg, G, act;         // Cv = CA + CB padded to 32 (padding channels are written as zero)
+    const float* stats;                     // [n][G][2] mean, rstd
+    const float* gamma; const float* beta;
+    bf16_t* out;                            // [n][HW][Cv]
+    int NB;
+};
+__global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
+    const int U = a.Cv >> 3;                                   // 8-channel units per pixel
+    const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
+    if (i >= (long)a.NB * a.HW * U) return;
+    const int u = (int)(i % U);
+    const long np = i / U;                                     // n * HW + p
+    const int n = (int)(np / a.HW);
+    const int Cin = a.CA + a.CB;
+    unsigned o[4];
 #pragma unroll
-    for (int cc = 0; cc < NCT; ++cc) {
-        const int col = col0 + cc * 16;
-        if (col >= a.Cout) continue;
-        float add = a.bias ? a.bias[col] : 0.f;
-        if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
-        float s1 = 0.f, s2 = 0.f;
+    for (int h = 0; h < 2; ++h) {
+        const int c = u * 8 + h * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < Cin) {
+            v = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + (size_t)np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + (size_t)np * a.CB + (c - a.CA));
+            const int grp = c / a.Cg;
+            const float mean = a.stats[((size_t)n * a.G + grp) * 2], rstd = a.stats[((size_t)n * a.G + grp) * 2 + 1];
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
 #pragma unroll
-        for (int i = 0; i < NMT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = i * 16 + kq * 4 + r;
-                const int opix = oy0 * a.Wo + m;
-                if (m < tile_px && opix < HWo) {
-                    const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
-                    float v = acc[i][cc][r] + add;
-                    if (a.resid) v += a.resid[o];
-                    v *= scale;
-                    a.out[o] = v;
-                    s1 += v; s2 += v * v;
-                }
-            }
-        if (a.chsum) {            // this lane's column over its rows, then over the four k-groups that hold the other rows of the tile
-            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-            if (kq == 0) {        // every (sample, tile, column) has exactly one writer: no atomics, run-to-run identical
-                float* cs = a.chsum + (((size_t)n * tiles_per_img + tile) * a.Cout + col) * 2;
-                cs[0] = s1; cs[1] = s2;
+            for (int j = 0; j < 4; ++j) {
+                const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
+                v[j] = a.act ? silu_f(y) : y;
             }
         }
+        o[2 * h] = pack_bf16x2(v[0], v[1]); o[2 * h + 1] = pack_bf16x2(v[2], v[3]);
     }
+    *reinterpret_cast<u32x4*>(a.out + (size_t)np * a.Cv + u * 8) = u32x4{o[0], o[1], o[2], o[3]};
+}
+
+// 3x3, stride 1, pad 1 over a pre-activated bf16 tensor (TConvArgs: srcA = that tensor, CA = Cv, CB = 0, stats = null).
+// Cv is a multiple of 64 (planner).  Same tiling as tconv_kernel; a slab is TP_KS = 64 channels ([pixel][64 + 8] bf16 in LDS: 144-byte rows keep the ds_read_b128
+// A fragments and the 16-byte staging stores conflict-free), staged as 16-byte copies that are register-prefetched one slab ahead.
+#define TP_KS 64
+#define TP_ROW (TP_KS + 8)
+__host__ __device__ inline size_t tconv_pre_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * TP_ROW * 2; }
+
+template <int NMT, int NCT>
+__global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int tiles_per_img = (a.Ho + a.TR - 1) / a.TR;
+    const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
+    const int oy0 = tile * a.TR;
+    const int col0 = blockIdx.y * (64 * NCT) + wave * (16 * NCT) + lrow;
+    const int TRv = a.TR + 2, Wl = a.Wo + 2, npix = TRv * Wl;
+    bf16_t* win = reinterpret_cast<bf16_t*>(rdmi_lds);
+    f32x4 acc[NMT][NCT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int pbase[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) {
+        const int m = min(i * 16 + lrow, a.TR * a.Wo - 1);
+        const int oyl = m / a.Wo, ox = m - oyl * a.Wo;
+        pbase[i] = oyl * Wl + ox;
+    }
+    // B fragments: wave-uniform (tap, k-step) block + 32-bit lane offset; A fragments: lane byte offset + wave-uniform tap offset
+    unsigned whoff[NCT];
+#pragma unroll
+    for (int cc = 0; cc < NCT; ++cc) {
+        const int cl = min(col0 + cc * 16, a.Cout_pad - 16 + lrow);
+        whoff[cc] = (unsigned)(cl * 32 + kq * 8) * 2u;
+    }
+    const size_t bstride = (size_t)a.Cout_pad * 32 * 2;             // bytes per (tap, 32-channel k-step) block
+    const int nk = a.Cv >> 5;
+    int lbase[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) lbase[i] = (pbase[i] * TP_ROW + kq * 8) * 2;
+    // staging geometry: unit i = tid + k * 256 is 8 channels (16 bytes) of window pixel i >> 3; source byte offset or -1
+    const int u8 = (tid & 7) * 8;
+    int soff[TC_MAXS];
+    const char* base = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(a.srcA) + (size_t)n * a.Ha * a.Wa * a.Cv);
+#pragma unroll
+    for (int k = 0; k < TC_MAXS; ++k) {
+        const int i = tid + k * RDMI_THREADS, p = i >> 3;
+        const int ry = p / Wl, rx = p - ry * Wl;
+        const int vy = oy0 - 1 + ry, vx = rx - 1;
+        soff[k] = (i < npix * 8 && vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv) ? ((vy * a.Wa + vx) * a.Cv + u8) * 2 : -1;
+    }
+    u32x4 raw[TC_MAXS];
+    auto fetch = [&](int c0) {
+        const bool cok = c0 + u8 < a.Cv;
+#pragma unroll
+        for (int k = 0; k < TC_MAXS; ++k) {
+            const bool ok = cok && soff[k] >= 0;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(base + (ok ? soff[k] + c0 * 2 : 0));
+            raw[k] = u32x4{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u};
+        }
+    };
+    // The 18 (tap, k-step) MFMA groups of a slab are unrolled with the B fragments in a ring of three register sets loaded two
+    // groups ahead (the first two before the slab's window is committed), so the weight loads' L2 latency is covered by MFMA work;
+    // sched_fence / opaque_sgpr keep the compiler from hoisting all 18 groups' loads and addresses (which spills).
+    auto loadB = [&](int t, int ks, int c0, u32x4 (&b)[NCT]) {
+        const char* blk = reinterpret_cast<const char*>(a.wpk) + ((size_t)t * nk + (c0 >> 5) + ks) * bstride;      // wave-uniform
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) b[cc] = *reinterpret_cast<const u32x4*>(blk + whoff[cc]);
+    };
+    auto mma = [&](int t, int ks, const u32x4 (&b)[NCT]) {
+        int toffb = (((t / 3) * Wl + (t % 3)) * TP_ROW + ks * 32) * 2;
+        opaque_sgpr(toffb);
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+            const u32x4 af = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(win) + lbase[i] + toffb);
+#pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = mfma16_bf16(af, b[cc], acc[i][cc]);
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < a.Cv; c0 += TP_KS) {
+        u32x4 br[3][NCT];
+        loadB(0, 0, c0, br[0]);
+        loadB(0, 1, c0, br[1]);
+#pragma unroll
+        for (int k = 0; k < TC_MAXS; ++k) {
+            const int i = tid + k * RDMI_THREADS;
+            if (i < npix * 8) *reinterpret_cast<u32x4*>(win + (size_t)(i >> 3) * TP_ROW + u8) = raw[k];
+        }
+        __syncthreads();
+        if (c0 + TP_KS < a.Cv) fetch(c0 + TP_KS);              // next slab's loads fly under this slab's MFMAs
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            if (j + 2 < 18) loadB((j + 2) >> 1, (j + 2) & 1, c0, br[(j + 2) % 3]);
+            mma(j >> 1, j & 1, br[j % 3]);
+            sched_fence();
+        }
+        __syncthreads();
+    }
+    tconv_epilogue<NMT, NCT>(a, acc, n, tile, tiles_per_img, oy0, col0, kq);
 }
 
 // GroupNorm statistics of concat(A, B) from the producers' per-tile channel sums: stats[n][g] = (mean, rstd) with the single-pass

@@ -487,3 +487,42 @@ def check_bf16_train(out, g):
     assert big.sum() >= 240
     assert np.abs(gn[big] / ref[big] - 1).max() < 4e-2, float(np.abs(gn[big] / ref[big] - 1).max())
     assert np.median(np.abs(gn[big] / ref[big] - 1)) < 1e-2
+
+
+def _small_rgb_model(ge, compute_dtype):
+    """A 16x16 RGB NCSN++ (nf=32, ch_mult [1,2,2], one block per level, attention at 8x8, scale_by_sigma): small enough for the
+    emulator, and -- more than one image channel -- planned by the spatially TILED plan like BASELINE config #5."""
+    from oracle.weights import make_params
+    from rdmi.models import utils as mutils
+    cfg = ge.demo_config(image_size=16, image_width=16)
+    m = cfg.model
+    m.nf, m.ch_mult, m.num_res_blocks, m.attn_resolutions = 32, [1, 2, 2], 1, [8]
+    m.channels, m.scale_by_sigma, m.compute_dtype = 3, True, compute_dtype
+    cfg.sde.sigma_max = 50
+    params = make_params(3, nf=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16, channels=3)
+    model = mutils.create_model(cfg)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    return model.eval(), params
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 2e-5), ('bf16', 3e-2)])
+def test_tiled_plan_small_rgb_model(emu, dtype, tol):
+    """The tiled plan (csrc/tiled_kernels.h: tconv, channel-sum GroupNorm statistics, batched-GEMM attention, and for bf16 the
+    pre-activated gn_act + tconv_pre pair) on the emulator against the torch oracle: classifier-free-guidance score of two samples.
+    Tolerance relative to each sample's largest |score|: fp32 2e-5; bf16 operands 3e-2 (stated bf16 tolerance, as on the GPU)."""
+    import __graft_entry__ as ge
+    from oracle import rd_oracle_torch as OT
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    model, params = _small_rgb_model(ge, dtype)
+    pt = {k: torch.from_numpy(v) for k, v in params.items()}
+    sde = sde_lib.RVESDE(0.01, 50, N=1000)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 16, 16, generator=g); lab = torch.zeros(2, 1); w = torch.tensor([0.0, 0.6]); t = torch.tensor([0.7, 0.2])
+    with torch.no_grad():
+        s = mutils.get_cf_score_fn(sde, model, lab, w)(x, t)
+        ref = OT.cf_score(pt, x, t, lab, w, smax=50.0, ch_mult=(1, 2, 2), nrb=1, attn_levels=(False, True, False), scale_by_sigma=True)
+    info = model._ctx[('cpu', 16, 16)].path_info()
+    assert info.startswith('tiled'), info
+    for n in range(2):
+        assert float((s[n] - ref[n]).abs().max()) <= tol * float(ref[n].abs().max()), (n, dtype)
