@@ -163,10 +163,11 @@ struct rdmi_ctx {
     // tiled plan (shapes whose samples do not fit one workgroup: csrc/tiled_kernels.h)
     struct TLaunch {
         int kind = 0;                 // 0 conv, 1 GroupNorm statistics (pass over the tensor), 2 batched GEMM, 3 softmax, 4 transpose, 5 statistics from channel sums,
-                                      // 6 GroupNorm(+SiLU) written once as bf16 for a pre-activated conv (bf16 plan)
+                                      // 6 GroupNorm(+SiLU) written once as bf16 for a pre-activated conv (bf16 plan), 7 fused softmax(QK^T)V (bf16 plan)
         std::string name;
         TConvArgs conv{}; int nmt = 4; bool pre = false;          // pre: input is the bf16 tensor a kind-6 launch wrote (tconv_pre_kernel)
         GnActArgs gact{};                                                                                       // kind 6
+        FlashArgs flash{}; int flashC = 0;                                                                      // kind 7: fused attention core (bf16 plan)
         const float *sA = nullptr, *sB = nullptr; int CA = 0, CB = 0, HW = 0, G = 0; float* stats = nullptr;     // kind 1
         BgemmArgs gemm{};                                                                                       // kind 2
         float* sm = nullptr; long rows_per_sample = 0; int L = 0;                                               // kind 3
@@ -634,9 +635,18 @@ struct TiledBuilder {
         const size_t bq = b.alloc_w((size_t)3 * C);
         for (int i = 0; i < 3; ++i) b.job_copy(name + ".NIN_" + std::to_string(i) + ".b", bq, C, i * C);
         TT qkv = conv(name + ".qkv", x, nullptr, &st, name + ".GroupNorm_0", false, 1, 1, false, o3, 3 * C, "", bq, -1, nullptr, 1.f, false);
-        TT S = talloc(Lq, Lq, 1);                    // [L][L] scores / probabilities
         TT Vt = talloc(C, Lq, 1);                    // [C][L]
         TT O = talloc(C, x.H, x.W);
+        const bool flash = bf16() && (C == 64 || C == 128 || C == 256) && Lq % 64 == 0 && std::getenv("RDMI_NO_FLASH") == nullptr;
+        if (flash) {
+            // bf16 plan: scores, softmax and P V in one kernel (no [L][L] buffer); V^T still comes from the transpose launch
+            { rdmi_ctx::TLaunch l; l.kind = 4; l.name = name + ".vT"; l.oA = qkv.off; l.oOut = Vt.off; l.tL = Lq; l.tC = C; l.tld = 3 * C; l.tc0 = 2 * C; c->tl.push_back(l); }
+            rdmi_ctx::TLaunch l; l.kind = 7; l.name = name + ".core"; l.oA = qkv.off; l.oB = Vt.off; l.oOut = O.off;
+            l.flash.L = Lq; l.flash.alpha = 1.0f / std::sqrt((float)C); l.flashC = C;
+            l.flops_per_sample = 4.0 * Lq * Lq * C;
+            c->tl.push_back(l);
+        } else {
+        TT S = talloc(Lq, Lq, 1);                    // [L][L] scores / probabilities
         {
             rdmi_ctx::TLaunch l; l.kind = 2; l.name = name + ".qk";
             l.oA = qkv.off; l.oB = qkv.off; l.dB = C; l.oC = S.off;
@@ -654,6 +664,7 @@ struct TiledBuilder {
             l.gemm.M = Lq; l.gemm.N = C; l.gemm.K = Lq; l.gemm.alpha = 1.f;
             l.flops_per_sample = 2.0 * Lq * Lq * C;
             c->tl.push_back(l);
+        }
         }
         return conv(name + ".NIN_3", O, nullptr, nullptr, "", false, 1, 1, false, pack1x1(name + ".NIN_3", C, C), C, name + ".NIN_3.b", (size_t)-1, -1, &x,
                     (float)(1.0 / std::sqrt(2.0)), false);
@@ -743,6 +754,8 @@ int finish_tiled_plan(rdmi_ctx* c) {
             l.sm = tl_ptr(c, l.oA);
         } else if (l.kind == 5) {
             l.sA = tl_ptr(c, l.oA); l.sB = tl_ptr(c, l.oB); l.stats = tl_ptr(c, l.oStats);
+        } else if (l.kind == 7) {
+            l.flash.qkv = tl_ptr(c, l.oA); l.flash.vt = tl_ptr(c, l.oB); l.flash.out = tl_ptr(c, l.oOut);
         } else if (l.kind == 6) {
             l.gact.A = tl_ptr(c, l.oA); l.gact.B = tl_ptr(c, l.oB); l.gact.stats = tl_ptr(c, l.oStats);
             l.gact.out = reinterpret_cast<bf16_t*>(tl_ptr(c, l.oOut));
@@ -1827,6 +1840,19 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             ProfScope ps(c, s, a.compute_dtype == 1 ? "bgemm_nt_bf16_kernel" : "bgemm_nt_kernel", l.flops_per_sample * NB);
             if (a.compute_dtype == 1) hipLaunchKernelGGL(bgemm_nt_bf16_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
             else hipLaunchKernelGGL(bgemm_nt_kernel, dim3((unsigned)ceil_div(l.gemm.M, 64), (unsigned)ceil_div(l.gemm.N, 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.gemm);
+        } else if (l.kind == 7) {
+            FlashArgs fa = l.flash; fa.NB = NB;
+            ProfScope ps(c, s, "flash_attn_bf16_kernel", l.flops_per_sample * NB);
+            const dim3 grid((unsigned)(fa.L / 64), (unsigned)NB);
+            static bool flash_attr = false;                          // 70 KB of dynamic LDS at C = 256
+            if (!flash_attr) {
+                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_bf16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_bf16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                flash_attr = true;
+            }
+            if (l.flashC == 256) hipLaunchKernelGGL(flash_attn_bf16_kernel<256>, grid, dim3(RDMI_THREADS), flash_lds_bytes<256>(), s, fa);
+            else if (l.flashC == 128) hipLaunchKernelGGL(flash_attn_bf16_kernel<128>, grid, dim3(RDMI_THREADS), flash_lds_bytes<128>(), s, fa);
+            else hipLaunchKernelGGL(flash_attn_bf16_kernel<64>, grid, dim3(RDMI_THREADS), flash_lds_bytes<64>(), s, fa);
         } else if (l.kind == 6) {
             GnActArgs g = l.gact; g.NB = NB;
             const long units = (long)NB * g.HW * (g.Cv / 8);
@@ -1834,7 +1860,7 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             hipLaunchKernelGGL(gn_act_kernel, dim3((unsigned)((units + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, g);
         } else if (l.kind == 5) {
             ProfScope ps(c, s, "gn_finalize_kernel", 0);
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NB), dim3(64), 0, s, l.sA, l.sB, l.CA, l.CB, l.tL, l.tC, l.HW, l.G, 1e-6f, l.stats);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, l.sA, l.sB, l.CA, l.CB, l.tL, l.tC, l.HW, l.G, 1e-6f, l.stats);
         } else if (l.kind == 3) {
             const long rows = l.rows_per_sample * NB;
             ProfScope ps(c, s, "softmax_rows_kernel", 0);
@@ -1842,6 +1868,9 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
         } else {
             const long n = (long)NB * l.tL * l.tC;
             ProfScope ps(c, s, "transpose_lc_kernel", 0);
+            if (l.tL % 64 == 0 && l.tC % 64 == 0)
+                hipLaunchKernelGGL(transpose_lc_tile_kernel, dim3((unsigned)(l.tL / 64), (unsigned)(l.tC / 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.tsrc, l.tdst, l.tL, l.tC, l.tld, l.tc0);
+            else
             hipLaunchKernelGGL(transpose_lc_kernel, dim3((unsigned)((n + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, l.tsrc, l.tdst, NB, l.tL, l.tC, l.tld, l.tc0);
         }
     }

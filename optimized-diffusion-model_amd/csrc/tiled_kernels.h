@@ -393,24 +393,34 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
 }
 
 // GroupNorm statistics of concat(A, B) from the producers' per-tile channel sums: stats[n][g] = (mean, rstd) with the single-pass
-// variance E[x^2] - mean^2 (fp32; activations are O(1)).  grid = NB, one work-item per group; tiles are added in a fixed order.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ csA, const float* __restrict__ csB, int CA, int CB, int tilesA, int tilesB,
-                                                         int HW, int G, float eps, float* __restrict__ stats) {
-    const int n = blockIdx.x, g = threadIdx.x;
-    if (g >= G) return;
+// variance E[x^2] - mean^2 (fp32; activations are O(1)).  grid = NB, 256 work-items.
+__global__ __launch_bounds__(RDMI_THREADS) void gn_finalize_kernel(const float* __restrict__ csA, const float* __restrict__ csB, int CA, int CB, int tilesA, int tilesB,
+                                                                    int HW, int G, float eps, float* __restrict__ stats) {
+    // eight lanes per group (G <= 32): lane `sub` adds the (channel, tile) pairs sub, sub + 8, ... in a fixed order, then the eight
+    // partial sums are merged by xor-shuffles -- the same order on every run
+    const int n = blockIdx.x, g = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const int C = CA + CB, Cg = C / G;
     float s1 = 0.f, s2 = 0.f;
-    for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
-        const bool inA = c < CA;
-        const float* cs = inA ? csA : csB;
-        const int Cx = inA ? CA : CB, cx = inA ? c : c - CA, tiles = inA ? tilesA : tilesB;
-        for (int t = 0; t < tiles; ++t) { const float* p = cs + (((size_t)n * tiles + t) * Cx + cx) * 2; s1 += p[0]; s2 += p[1]; }
+    if (g < G) {
+        const int tmax = max(tilesA, tilesB);
+        for (int e = sub; e < Cg * tmax; e += 8) {
+            const int cc = e / tmax, t = e - cc * tmax, c = g * Cg + cc;
+            const bool inA = c < CA;
+            const int tiles = inA ? tilesA : tilesB;
+            if (t < tiles) {
+                const float* p = (inA ? csA : csB) + (((size_t)n * tiles + t) * (inA ? CA : CB) + (inA ? c : c - CA)) * 2;
+                s1 += p[0]; s2 += p[1];
+            }
+        }
     }
-    const float cnt = (float)(Cg * HW);
-    const float mean = s1 / cnt;
-    const float var = fmaxf(s2 / cnt - mean * mean, 0.f);
-    stats[((size_t)n * G + g) * 2] = mean;
-    stats[((size_t)n * G + g) * 2 + 1] = 1.0f / sqrtf(var + eps);
+    for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+    if (g < G && sub == 0) {
+        const float cnt = (float)(Cg * HW);
+        const float mean = s1 / cnt;
+        const float var = fmaxf(s2 / cnt - mean * mean, 0.f);
+        stats[((size_t)n * G + g) * 2] = mean;
+        stats[((size_t)n * G + g) * 2 + 1] = 1.0f / sqrtf(var + eps);
+    }
 }
 
 // mean / rstd of GroupNorm group g of sample n over concat(A, B): grid = (G, NB); two passes (exact like F.group_norm)
@@ -524,6 +534,105 @@ __global__ __launch_bounds__(RDMI_THREADS) void softmax_rows_kernel(float* __res
     for (int i = lane; i < L; i += 64) p[i] *= inv;
 }
 
+// ---- bf16 plan: softmax(Q K^T / sqrt(C)) V in one kernel (AttnBlockpp, RD/models/layerspp.py:84-92) -----------------------------
+// Replaces bgemm (scores) + softmax_rows + bgemm (P V) and the [L][L] score buffer.  grid (L / 64, NB), 4 waves; wave w owns the 16
+// queries 64 * blockIdx.x + 16 w.  Everything is computed TRANSPOSED so that no accumulator ever has to change layout:
+//   S^T tile (16 keys x 16 queries) = K_tile (A operand: row = key) . Q^T (B operand: column = query, kept in registers, pre-scaled)
+//   -> a lane holds, for ITS query (lane & 15), the keys 16 T + 4 (lane >> 4) + r: online softmax needs only two cross-lane steps;
+//   O^T tile (16 channels x 16 queries) += V^T_tile (A: row = channel) . P^T (B: column = query): the contraction runs over keys
+//   in the order the lane already holds them (slots 0..3 <- tile 2s, 4..7 <- tile 2s + 1), and the V^T fragment is read from LDS in
+//   that same order (two ds_read_b64), so P goes from accumulator to operand with a bf16 conversion only.
+// K blocks of 64 keys are staged as [key][C + 8] bf16, V^T blocks (from the [C][L] transpose the plan already makes) as
+// [channel][64 + 8] bf16; fp32 running max / sum / output accumulators.
+struct FlashArgs { const float* qkv; const float* vt; float* out; int L, NB; float alpha; };   // qkv [n][L][3C] (q | k | v), vt [n][C][L], out [n][L][C]
+template <int C>
+__host__ __device__ inline size_t flash_lds_bytes() { return ((size_t)64 * (C + 8) + (size_t)C * 72) * 2; }
+
+template <int C>
+__global__ __launch_bounds__(RDMI_THREADS) void flash_attn_bf16_kernel(FlashArgs a) {
+    constexpr int KS = C / 32, UT = C / 16, KR = C + 8, VR = 72;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int n = blockIdx.y, q = blockIdx.x * 64 + wave * 16 + l15;
+    bf16_t* Kl = reinterpret_cast<bf16_t*>(rdmi_lds);        // [64][KR]
+    bf16_t* Vl = Kl + 64 * KR;                                // [C][VR]
+    const float* qkv = a.qkv + (size_t)n * a.L * 3 * C;
+    const float* vt = a.vt + (size_t)n * C * a.L;
+    // this lane's query fragments (B operand): channels 32 s + 8 g .. + 7, pre-scaled by 1 / sqrt(C)
+    u32x4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(qkv + (size_t)q * 3 * C + 32 * s + 8 * g);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(qkv + (size_t)q * 3 * C + 32 * s + 8 * g + 4);
+        qf[s] = u32x4{pack_bf16x2(v0[0] * a.alpha, v0[1] * a.alpha), pack_bf16x2(v0[2] * a.alpha, v0[3] * a.alpha),
+                      pack_bf16x2(v1[0] * a.alpha, v1[1] * a.alpha), pack_bf16x2(v1[2] * a.alpha, v1[3] * a.alpha)};
+    }
+    f32x4 o[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -3.0e38f, lsum = 0.f;
+    typedef unsigned int u32x2 __attribute__((vector_size(8)));
+    for (int kb = 0; kb < a.L; kb += 64) {
+        __syncthreads();                                       // previous block fully consumed
+#pragma unroll 4
+        for (int it = 0; it < C / 16; ++it) {                  // K block: 64 keys x C channels (4 loads in flight: the accumulators need the registers)
+            const int idx = tid + it * RDMI_THREADS, key = idx / (C / 4), c4 = idx - key * (C / 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (size_t)(kb + key) * 3 * C + C + 4 * c4);
+            *reinterpret_cast<u32x2*>(Kl + key * KR + 4 * c4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+#pragma unroll 4
+        for (int it = 0; it < C / 16; ++it) {                  // V^T block: C channels x 64 keys
+            const int idx = tid + it * RDMI_THREADS, c = idx >> 4, k4 = idx & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vt + (size_t)c * a.L + kb + 4 * k4);
+            *reinterpret_cast<u32x2*>(Vl + c * VR + 4 * k4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+        __syncthreads();
+        // S^T: four key tiles x KS k-steps
+        f32x4 st[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Kl + (16 * t + l15) * KR + 32 * s + 8 * g);
+                st[t] = mfma16_bf16(kf, qf[s], st[t]);
+            }
+        // online softmax over this lane's 16 keys, then over the four k-groups that hold the same query
+        float mx = m;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float corr = __expf(m - mx);
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[t][r] = __expf(st[t][r] - mx); ps += st[t][r]; }
+        ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+        lsum = lsum * corr + ps; m = mx;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) o[u] *= corr;
+        // O^T += V^T . P^T: two k-steps of 32 keys (tiles 2 s2, 2 s2 + 1)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x4 pf = u32x4{pack_bf16x2(st[2 * s2][0], st[2 * s2][1]), pack_bf16x2(st[2 * s2][2], st[2 * s2][3]),
+                                   pack_bf16x2(st[2 * s2 + 1][0], st[2 * s2 + 1][1]), pack_bf16x2(st[2 * s2 + 1][2], st[2 * s2 + 1][3])};
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                const bf16_t* vr = Vl + (16 * u + l15) * VR + 32 * s2 + 4 * g;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vr), hi = *reinterpret_cast<const u32x2*>(vr + 16);
+                o[u] = mfma16_bf16(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf, o[u]);
+            }
+        }
+    }
+    const float inv = 1.0f / lsum;
+    float* og = a.out + ((size_t)n * a.L + q) * C;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) *reinterpret_cast<f32x4*>(og + 16 * u + 4 * g) = o[u] * inv;
+}
+
 // dst[n][c][l] = src[n][l][c0 + c] (row stride lds_): V -> V^T for the P V product
 __global__ __launch_bounds__(RDMI_THREADS) void transpose_lc_kernel(const float* __restrict__ src, float* __restrict__ dst, int NB, int L, int C, int ld, int c0) {
     const long i = (long)blockIdx.x * RDMI_THREADS + threadIdx.x;
@@ -533,6 +642,18 @@ __global__ __launch_bounds__(RDMI_THREADS) void transpose_lc_kernel(const float*
     const int c = (int)(r % C);
     const long n = r / C;
     dst[i] = src[((size_t)n * L + l) * ld + c0 + c];
+}
+
+// same through a 64 x 64 LDS tile (L, C multiples of 64): both the strided read and the write are 256-byte runs.  grid (L/64, C/64, NB)
+__global__ __launch_bounds__(RDMI_THREADS) void transpose_lc_tile_kernel(const float* __restrict__ src, float* __restrict__ dst, int L, int C, int ld, int c0) {
+    __shared__ float tile[64][65];
+    const int l0 = blockIdx.x * 64, cb = blockIdx.y * 64, n = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = src[((size_t)n * L + l0 + r) * ld + c0 + cb + tx];
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) dst[((size_t)n * C + cb + r) * L + l0 + tx] = tile[tx][r];
 }
 
 // API boundary for channels > 1: NCHW (the reference's layout) <-> NHWC
