@@ -515,7 +515,7 @@ int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, in
 struct TiledBuilder {
     rdmi_ctx* c; Builder& b;
     size_t top = 0;                                   // floats per sample allocated so far
-    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0; };   // cs: per-tile channel sums of the producer
+    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0; bool bf = false; };   // cs: per-tile channel sums of the producer; bf: a bf16 [HW][C] tensor (C % 64 == 0) for tconv_pre
     TT talloc(int C, int H, int W) { TT t; t.off = top; t.C = C; t.H = H; t.W = W; t.valid = true; top += ((size_t)C * H * W + 63) & ~(size_t)63; return t; }
     static int pad32(int a) { return (a + 31) & ~31; }
 
@@ -557,11 +557,14 @@ struct TiledBuilder {
             size_t w_off, int cout, const std::string& bias_param, size_t bias_arena, int dense_off, const TT* resid, float scale, bool final_out) {
         // bf16 plan: a 3x3 stride-1 conv behind a GroupNorm reads a tensor that was normalised, activated and rounded to bf16 ONCE
         // (kind 6) instead of redoing that arithmetic for every staged window element (RDMI_NO_PREACT=1: the one-kernel form)
-        const bool pre = bf16() && st && ntap == 9 && stride == 1 && !up && !final_out && cout % 16 == 0 && A.C % 4 == 0 && (!B || B->C % 4 == 0) &&
-                         (A.C + (B ? B->C : 0)) % 64 == 0 &&
-                         std::getenv("RDMI_NO_PREACT") == nullptr;
-        size_t act_off = 0;
-        if (pre) {
+        // (3x3 stride-1 convs and the 1x1 q/k/v projection of attention blocks); a tensor that already is bf16 (the fused attention
+        // core's output) goes to the same kernel without the extra pass.
+        const bool direct = A.bf && !B && !st && ntap == 1;
+        const bool pre = direct || (bf16() && st && (ntap == 9 || ntap == 1) && stride == 1 && !up && !final_out && cout % 16 == 0 && A.C % 4 == 0 &&
+                                    (!B || B->C % 4 == 0) && (A.C + (B ? B->C : 0)) % 64 == 0 && std::getenv("RDMI_NO_PREACT") == nullptr);
+        if (A.bf && !direct) throw std::runtime_error("tiled plan: a bf16 tensor feeds a conv that cannot take it (" + name + ")");
+        size_t act_off = A.off;
+        if (pre && !direct) {
             const int Cin = A.C + (B ? B->C : 0), Cvp = pad32(Cin);
             TT actT = talloc((Cvp + 1) / 2, A.H, A.W);               // bf16 [HW][Cv]
             act_off = actT.off;
@@ -638,11 +641,12 @@ struct TiledBuilder {
         TT Vt = talloc(C, Lq, 1);                    // [C][L]
         TT O = talloc(C, x.H, x.W);
         const bool flash = bf16() && (C == 64 || C == 128 || C == 256) && Lq % 64 == 0 && std::getenv("RDMI_NO_FLASH") == nullptr;
+        if (flash) { O.bf = true; }                  // written as bf16 [L][C] (half of the allocation): NIN_3 stages plain copies of it
         if (flash) {
             // bf16 plan: scores, softmax and P V in one kernel (no [L][L] buffer); V^T still comes from the transpose launch
             { rdmi_ctx::TLaunch l; l.kind = 4; l.name = name + ".vT"; l.oA = qkv.off; l.oOut = Vt.off; l.tL = Lq; l.tC = C; l.tld = 3 * C; l.tc0 = 2 * C; c->tl.push_back(l); }
             rdmi_ctx::TLaunch l; l.kind = 7; l.name = name + ".core"; l.oA = qkv.off; l.oB = Vt.off; l.oOut = O.off;
-            l.flash.L = Lq; l.flash.alpha = 1.0f / std::sqrt((float)C); l.flashC = C;
+            l.flash.L = Lq; l.flash.alpha = 1.0f / std::sqrt((float)C); l.flashC = C; l.flash.out_bf16 = 1;
             l.flops_per_sample = 4.0 * Lq * Lq * C;
             c->tl.push_back(l);
         } else {
@@ -743,6 +747,8 @@ int finish_tiled_plan(rdmi_ctx* c) {
             a.wpk = c->d_w + l.w_off;
             a.dense = l.use_dense ? c->d_dense : nullptr;
             a.chsum = tl_ptr(c, l.oC);
+            if (l.pre && tconv_trv(a) * tconv_wl(a) * (a.ntap == 1 ? TpCfg<1>::UPP : TpCfg<9>::UPP) > TC_MAXS * RDMI_THREADS)
+                return fail("tiled conv %s: window of %d pixels exceeds the register staging", l.name.c_str(), tconv_trv(a) * tconv_wl(a));
             if (l.pre && tconv_pre_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_pre_lds_bytes(a));
             if (tconv_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_lds_bytes(a));
             if (tconv_trv(a) * tconv_wl(a) * 8 > TC_MAXS * RDMI_THREADS) return fail("tiled conv %s: window of %d pixels exceeds the register staging (%d float4 per work-item)", l.name.c_str(), tconv_trv(a) * tconv_wl(a), TC_MAXS);
@@ -1818,7 +1824,11 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             const bool h = a.compute_dtype == 1;
             const size_t lds = l.pre ? tconv_pre_lds_bytes(ca) : h ? tconv_bf16_lds_bytes(ca) : tconv_lds_bytes(ca);
             ProfScope ps(c, s, l.pre ? "tconv_pre_kernel<bf16>" : h ? "tconv_kernel<bf16>" : "tconv_kernel<fp32>", l.flops_per_sample * NB);
-#define RDMI_TCONV_PRE(NMT_, NCT_) hipLaunchKernelGGL((tconv_pre_kernel<NMT_, NCT_>), grid, dim3(RDMI_THREADS), lds, s, ca)
+#define RDMI_TCONV_PRE(NMT_, NCT_)                                                                                                    \
+    do {                                                                                                                              \
+        if (ca.ntap == 1) hipLaunchKernelGGL((tconv_pre_kernel<NMT_, NCT_, 1>), grid, dim3(RDMI_THREADS), lds, s, ca);                \
+        else hipLaunchKernelGGL((tconv_pre_kernel<NMT_, NCT_, 9>), grid, dim3(RDMI_THREADS), lds, s, ca);                             \
+    } while (0)
             if (l.pre) {
                 if (l.nmt == 4) { if (nct == 4) RDMI_TCONV_PRE(4, 4); else if (nct == 2) RDMI_TCONV_PRE(4, 2); else RDMI_TCONV_PRE(4, 1); }
                 else { if (nct == 4) RDMI_TCONV_PRE(1, 4); else if (nct == 2) RDMI_TCONV_PRE(1, 2); else RDMI_TCONV_PRE(1, 1); }

@@ -289,35 +289,34 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
     *reinterpret_cast<u32x4*>(a.out + (size_t)np * a.Cv + u * 8) = u32x4{o[0], o[1], o[2], o[3]};
 }
 
-// 3x3, stride 1, pad 1 over a pre-activated bf16 tensor (TConvArgs: srcA = that tensor, CA = Cv, CB = 0, stats = null).
-// Cv is a multiple of 64 (planner).  Same tiling as tconv_kernel; a slab is TP_KS = 64 channels ([pixel][64 + 8] bf16 in LDS: 144-byte rows keep the ds_read_b128
-// A fragments and the 16-byte staging stores conflict-free), staged as 16-byte copies that are register-prefetched one slab ahead.
-#define TP_KS 64
-#define TP_ROW (TP_KS + 8)
-__host__ __device__ inline size_t tconv_pre_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * TP_ROW * 2; }
+// 3x3 (stride 1, pad 1) or 1x1 conv over a bf16 tensor that is already normalised / activated (TConvArgs: srcA = that tensor,
+// CA = Cv, CB = 0, stats = null; Cv a multiple of 64 -- planner).  Same tiling as tconv_kernel.  A slab is KS channels of the
+// window ([pixel][KS + 8] bf16 in LDS: the +8 keeps the ds_read_b128 A fragments and the 16-byte staging stores conflict-free),
+// staged as 16-byte copies that are register-prefetched one slab ahead; KS = 64 for 3x3 (18 MFMA groups per slab), 256 for 1x1
+// (8 groups: a whole NIN contraction in one or two barrier pairs).
+template <int NTAP> struct TpCfg { static constexpr int KS = NTAP == 1 ? 256 : 64, ROW = KS + 8, UPP = KS / 8, GROUPS = NTAP * (KS / 32); };
+__host__ __device__ inline size_t tconv_pre_lds_bytes(const TConvArgs& a) {
+    const int row = a.ntap == 1 ? TpCfg<1>::ROW : TpCfg<9>::ROW;
+    return (size_t)tconv_trv(a) * tconv_wl(a) * row * 2;
+}
 
-template <int NMT, int NCT>
+template <int NMT, int NCT, int NTAP>
 __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
+    constexpr int KS = TpCfg<NTAP>::KS, ROW = TpCfg<NTAP>::ROW, UPP = TpCfg<NTAP>::UPP, GROUPS = TpCfg<NTAP>::GROUPS, KSTEPS = KS / 32;
+    constexpr int HALO = NTAP == 9 ? 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kq = lane >> 4;
     const int tiles_per_img = (a.Ho + a.TR - 1) / a.TR;
     const int n = blockIdx.x / tiles_per_img, tile = blockIdx.x - n * tiles_per_img;
     const int oy0 = tile * a.TR;
     const int col0 = blockIdx.y * (64 * NCT) + wave * (16 * NCT) + lrow;
-    const int TRv = a.TR + 2, Wl = a.Wo + 2, npix = TRv * Wl;
+    const int TRv = a.TR + 2 * HALO, Wl = a.Wo + 2 * HALO, npix = TRv * Wl;
     bf16_t* win = reinterpret_cast<bf16_t*>(rdmi_lds);
     f32x4 acc[NMT][NCT];
 #pragma unroll
     for (int i = 0; i < NMT; ++i)
 #pragma unroll
         for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int pbase[NMT];
-#pragma unroll
-    for (int i = 0; i < NMT; ++i) {
-        const int m = min(i * 16 + lrow, a.TR * a.Wo - 1);
-        const int oyl = m / a.Wo, ox = m - oyl * a.Wo;
-        pbase[i] = oyl * Wl + ox;
-    }
     // B fragments: wave-uniform (tap, k-step) block + 32-bit lane offset; A fragments: lane byte offset + wave-uniform tap offset
     unsigned whoff[NCT];
 #pragma unroll
@@ -329,17 +328,21 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
     const int nk = a.Cv >> 5;
     int lbase[NMT];
 #pragma unroll
-    for (int i = 0; i < NMT; ++i) lbase[i] = (pbase[i] * TP_ROW + kq * 8) * 2;
-    // staging geometry: unit i = tid + k * 256 is 8 channels (16 bytes) of window pixel i >> 3; source byte offset or -1
-    const int u8 = (tid & 7) * 8;
+    for (int i = 0; i < NMT; ++i) {
+        const int m = min(i * 16 + lrow, a.TR * a.Wo - 1);
+        const int oyl = m / a.Wo, ox = m - oyl * a.Wo;
+        lbase[i] = ((oyl * Wl + ox) * ROW + kq * 8) * 2;
+    }
+    // staging geometry: unit i = tid + k * 256 is 8 channels (16 bytes) of window pixel i / UPP; source byte offset or -1
+    const int u8 = (tid % UPP) * 8;
     int soff[TC_MAXS];
     const char* base = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(a.srcA) + (size_t)n * a.Ha * a.Wa * a.Cv);
 #pragma unroll
     for (int k = 0; k < TC_MAXS; ++k) {
-        const int i = tid + k * RDMI_THREADS, p = i >> 3;
+        const int i = tid + k * RDMI_THREADS, p = i / UPP;
         const int ry = p / Wl, rx = p - ry * Wl;
-        const int vy = oy0 - 1 + ry, vx = rx - 1;
-        soff[k] = (i < npix * 8 && vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv) ? ((vy * a.Wa + vx) * a.Cv + u8) * 2 : -1;
+        const int vy = oy0 - HALO + ry, vx = rx - HALO;
+        soff[k] = (i < npix * UPP && vy >= 0 && vy < a.Hv && vx >= 0 && vx < a.Wv) ? ((vy * a.Wa + vx) * a.Cv + u8) * 2 : -1;
     }
     u32x4 raw[TC_MAXS];
     auto fetch = [&](int c0) {
@@ -351,16 +354,20 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
             raw[k] = u32x4{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u};
         }
     };
-    // The 18 (tap, k-step) MFMA groups of a slab are unrolled with the B fragments in a ring of three register sets loaded two
+    // The (tap, k-step) MFMA groups of a slab are unrolled with the B fragments in a ring of three register sets loaded two
     // groups ahead (the first two before the slab's window is committed), so the weight loads' L2 latency is covered by MFMA work;
-    // sched_fence / opaque_sgpr keep the compiler from hoisting all 18 groups' loads and addresses (which spills).
-    auto loadB = [&](int t, int ks, int c0, u32x4 (&b)[NCT]) {
-        const char* blk = reinterpret_cast<const char*>(a.wpk) + ((size_t)t * nk + (c0 >> 5) + ks) * bstride;      // wave-uniform
+    // sched_fence / opaque_sgpr keep the compiler from hoisting every group's loads and addresses (which spills).
+    // Group j = (tap j / KSTEPS, k-step j % KSTEPS); k-steps beyond the tensor's channels (1x1 over fewer than 256) are skipped.
+    auto loadB = [&](int j, int c0, u32x4 (&b)[NCT]) {
+        const int t = j / KSTEPS, ks = j % KSTEPS;
+        const int kstep = min((c0 >> 5) + ks, nk - 1);          // clamped: a skipped group still loads a valid block
+        const char* blk = reinterpret_cast<const char*>(a.wpk) + ((size_t)t * nk + kstep) * bstride;      // wave-uniform
 #pragma unroll
         for (int cc = 0; cc < NCT; ++cc) b[cc] = *reinterpret_cast<const u32x4*>(blk + whoff[cc]);
     };
-    auto mma = [&](int t, int ks, const u32x4 (&b)[NCT]) {
-        int toffb = (((t / 3) * Wl + (t % 3)) * TP_ROW + ks * 32) * 2;
+    auto mma = [&](int j, const u32x4 (&b)[NCT]) {
+        const int t = j / KSTEPS, ks = j % KSTEPS;
+        int toffb = (((t / 3) * Wl + (t % 3)) * ROW + ks * 32) * 2;
         opaque_sgpr(toffb);
 #pragma unroll
         for (int i = 0; i < NMT; ++i) {
@@ -370,21 +377,22 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
         }
     };
     fetch(0);
-    for (int c0 = 0; c0 < a.Cv; c0 += TP_KS) {
+    for (int c0 = 0; c0 < a.Cv; c0 += KS) {
         u32x4 br[3][NCT];
-        loadB(0, 0, c0, br[0]);
-        loadB(0, 1, c0, br[1]);
+        loadB(0, c0, br[0]);
+        loadB(1, c0, br[1]);
 #pragma unroll
         for (int k = 0; k < TC_MAXS; ++k) {
             const int i = tid + k * RDMI_THREADS;
-            if (i < npix * 8) *reinterpret_cast<u32x4*>(win + (size_t)(i >> 3) * TP_ROW + u8) = raw[k];
+            if (i < npix * UPP) *reinterpret_cast<u32x4*>(win + (size_t)(i / UPP) * ROW + u8) = raw[k];
         }
         __syncthreads();
-        if (c0 + TP_KS < a.Cv) fetch(c0 + TP_KS);              // next slab's loads fly under this slab's MFMAs
+        if (c0 + KS < a.Cv) fetch(c0 + KS);                    // next slab's loads fly under this slab's MFMAs
+        const int ksteps = min(KSTEPS, nk - (c0 >> 5));
 #pragma unroll
-        for (int j = 0; j < 18; ++j) {
-            if (j + 2 < 18) loadB((j + 2) >> 1, (j + 2) & 1, c0, br[(j + 2) % 3]);
-            mma(j >> 1, j & 1, br[j % 3]);
+        for (int j = 0; j < GROUPS; ++j) {
+            if (j + 2 < GROUPS) loadB(j + 2, c0, br[(j + 2) % 3]);
+            if (KSTEPS == 2 || (j % KSTEPS) < ksteps) mma(j, br[j % 3]);      // Cv % 64 == 0: a 64-channel slab is always whole
             sched_fence();
         }
         __syncthreads();
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void softmax_rows_kernel(float* __res
 //   that same order (two ds_read_b64), so P goes from accumulator to operand with a bf16 conversion only.
 // K blocks of 64 keys are staged as [key][C + 8] bf16, V^T blocks (from the [C][L] transpose the plan already makes) as
 // [channel][64 + 8] bf16; fp32 running max / sum / output accumulators.
-struct FlashArgs { const float* qkv; const float* vt; float* out; int L, NB; float alpha; };   // qkv [n][L][3C] (q | k | v), vt [n][C][L], out [n][L][C]
+struct FlashArgs { const float* qkv; const float* vt; float* out; int L, NB; float alpha; int out_bf16; };   // qkv [n][L][3C] (q | k | v), vt [n][C][L], out [n][L][C] (fp32, or bf16 for a tconv_pre consumer)
 template <int C>
 __host__ __device__ inline size_t flash_lds_bytes() { return ((size_t)64 * (C + 8) + (size_t)C * 72) * 2; }
 
@@ -628,6 +636,15 @@ __global__ __launch_bounds__(RDMI_THREADS) void flash_attn_bf16_kernel(FlashArgs
         }
     }
     const float inv = 1.0f / lsum;
+    if (a.out_bf16) {
+        bf16_t* ob = reinterpret_cast<bf16_t*>(a.out) + ((size_t)n * a.L + q) * C;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const f32x4 v = o[u] * inv;
+            *reinterpret_cast<u32x2*>(ob + 16 * u + 4 * g) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+        return;
+    }
     float* og = a.out + ((size_t)n * a.L + q) * C;
 #pragma unroll
     for (int u = 0; u < UT; ++u) *reinterpret_cast<f32x4*>(og + 16 * u + 4 * g) = o[u] * inv;
