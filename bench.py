@@ -303,7 +303,18 @@ def train_variant(ge, dev, B, steps=10, dtype='f32'):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     assert bool(torch.isfinite(loss.detach()))
     tf = 3 * GFLOP_PER_FORWARD * B / dt / 1e3
-    return {'ms_per_step': 1e3 * dt, 'samples_per_s': B / dt, 'batch': B, 'dtype': dtype, 'tflops': tf,
+    hbm = {}
+    try:            # HBM bytes of one step (every kernel; PMC FETCH_SIZE x2 + WRITE_SIZE, scripts/gpu_pmc_train.sh), valid for these kernel sources only
+        with open(os.path.join(ROOT, 'profiles', 'train_traffic.json')) as f:
+            t = json.load(f)
+        if t.get('batch') == B and t.get('dtype') == dtype:
+            if t.get('csrc_sha16') == csrc_sha16():
+                hbm = {'hbm_bytes_per_step': t['bytes_per_step'], 'hbm_gbps': t['bytes_per_step'] / dt / 1e9}
+            else:
+                hbm = {'hbm_bytes_per_step': None, 'hbm_note': f"stale: measured on csrc {t.get('csrc_sha16')}"}
+    except Exception:                                            # noqa: BLE001
+        pass
+    return {**hbm, 'ms_per_step': 1e3 * dt, 'samples_per_s': B / dt, 'batch': B, 'dtype': dtype, 'tflops': tf,
             'frac': tf / (PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else 2500.0), 'peak_tflops': PEAK_FP32_MFMA_TFLOPS if dtype == 'f32' else 2500.0,
             'loss': float(loss.detach()),
             'what': 'train-mode forward + score-matching loss + backward + clip_grad_norm_ + Adam + EMA, steps timed back to back'}

@@ -38,7 +38,8 @@ def emu():
     from tests.emu.build_emu import build
     from rdmi import _native
     prev = (_native._lib, _native._lib_path)
-    _native.use_library(build())
+    # RDMI_EMU_ASAN=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0): the AddressSanitizer build
+    _native.use_library(build(sanitize=bool(os.environ.get('RDMI_EMU_ASAN'))))
     assert _native.is_emulator()
     yield _native
     _native._lib, _native._lib_path = prev
