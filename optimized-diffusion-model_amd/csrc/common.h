@@ -70,6 +70,16 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16_bf16(u32x4, u32x4, f32x4 c) { abort(); return c; }      // host pass of hipcc: never executed
 #endif
 #endif
+// wave_order_point: program order between LDS accesses of DIFFERENT lanes of one wave.  On the GPU a wave's LDS instructions execute in
+// issue order for all 64 lanes, so this is only a compiler fence; the CPU emulator runs lanes as independent fibers and needs a real
+// rendezvous.  Every lane of the wave must reach it.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void wave_order_point() { __builtin_amdgcn_wave_barrier(); }
+#elif defined(RDMI_EMU)
+__device__ __forceinline__ void wave_order_point() { int z = 0; (void)emu::wave_exchange(&z, sizeof z); }
+#else
+__device__ __forceinline__ void wave_order_point() {}
+#endif
 // compiler fences (no instructions): sched_fence keeps the machine scheduler from moving code across it; opaque_sgpr makes a
 // wave-uniform value opaque to the optimiser so that addresses derived from it are recomputed where used instead of hoisted
 #if defined(__HIP_DEVICE_COMPILE__)

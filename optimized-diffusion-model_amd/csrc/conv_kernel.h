@@ -78,7 +78,9 @@ __host__ __device__ inline size_t conv_lds_bytes(const ConvArgs& a) {
 __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const float* __restrict__ A,
                                            const float* __restrict__ B, const int* __restrict__ map, int CA,
                                            int CB, int Cpad, int HWsrc, int HWdst, int S, int n0, int NB,
-                                           int a_mod, int tid, int a_bf = 0, int b_bf = 0) {
+                                           int a_mod, int tid, int a_bf = 0, int b_bf = 0, int lds_bf16 = 0) {
+    // lds_bf16: the row keeps its byte stride (rs floats) but holds bf16 values in its first Cpad * 2 bytes -- the layout the bf16
+    // GEMM reads (a lane's A fragment of v_mfma_f32_16x16x32_bf16 is then ONE ds_read_b128 and no conversion)
     const int c4n = Cpad >> 2;
     const int total = S * HWdst * c4n;
     const int dpv = RDMI_THREADS / c4n, dc4 = RDMI_THREADS - dpv * c4n;
@@ -103,11 +105,16 @@ __device__ __forceinline__ void conv_stage(float* __restrict__ L, int rs, const 
                 val = ldact4(B, ((size_t)n * HWdst + v) * CB + (c - CA), b_bf);
             }
         }
-        *reinterpret_cast<f32x4*>(L + (size_t)pv * rs + c) = val;
+        if (lds_bf16) {
+            typedef unsigned int u32x2 __attribute__((vector_size(8)));
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(L + (size_t)pv * rs) + c) = u32x2{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+        } else {
+            *reinterpret_cast<f32x4*>(L + (size_t)pv * rs + c) = val;
+        }
         pv += dpv; c4 += dc4;
         if (c4 >= c4n) { c4 -= c4n; ++pv; }
     }
-    for (int i = tid; i < rs; i += RDMI_THREADS) L[(size_t)S * HWdst * rs + i] = 0.f;   // the zero row
+    for (int i = tid; i < rs; i += RDMI_THREADS) L[(size_t)S * HWdst * rs + i] = 0.f;   // the zero row (all-zero bits in either layout)
 }
 
 // The GEMM + epilogue for a wave that owns NMT row tiles (compile-time) x NT column tiles.
@@ -131,12 +138,11 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
         for (int i = 0; i < NMT; ++i) trow[i] = ((wm + i * WM) * 16 + lrow) * tw;
 
         if (BF16) {
-            // bf16 operands (v_mfma_f32_16x16x32_bf16): a step is 32 channels of one tap; the A fragment is 8 consecutive fp32 of the
-            // activated LDS row rounded to bf16 on the fly, the B fragment 16 bytes of the bf16 weight copy
-            auto afrag = [](const float* p) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(p), y = *reinterpret_cast<const f32x4*>(p + 4);
-                return u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
-            };
+            // bf16 operands (v_mfma_f32_16x16x32_bf16): a step is 32 channels of one tap; the LDS rows already hold bf16 (row byte
+            // stride unchanged: 2 * rs bf16 elements), so the A fragment is one ds_read_b128; the B fragment 16 bytes of the bf16 weights
+            const bf16_t* X16 = reinterpret_cast<const bf16_t*>(X);
+            const bf16_t* XS16 = reinterpret_cast<const bf16_t*>(XS);
+            const int rs16 = 2 * rs, rss16 = 2 * rss;
             {
                 const int nch = a.Cv >> 5;
                 const int nsteps = a.ntap * nch;
@@ -152,7 +158,7 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
                 int ph = wk / nch, ch = wk - ph * nch;
                 int abase[NMT > 0 ? NMT : 1];
 #pragma unroll
-                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs + kq * 8;
+                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs16 + kq * 8;
                 for (int q = wk; q < nsteps; q += PF * WK) {
 #pragma unroll
                     for (int u = 0; u < PF; ++u) {
@@ -160,7 +166,7 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
                         if (qq < nsteps) {
 #pragma unroll
                             for (int i = 0; i < NMT; ++i) {
-                                const u32x4 af = afrag(X + abase[i] + ch * 32);
+                                const u32x4 af = *reinterpret_cast<const u32x4*>(X16 + abase[i] + ch * 32);
 #pragma unroll
                                 for (int t = 0; t < NT; ++t) acc[i][t] = mfma16_bf16(af, bring[u][t], acc[i][t]);
                             }
@@ -174,7 +180,7 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
                                 ch -= nch; ++ph;
                                 if (ph < a.ntap) {
 #pragma unroll
-                                    for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs + kq * 8;
+                                    for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + ph] * rs16 + kq * 8;
                                 }
                             }
                         }
@@ -187,14 +193,14 @@ __device__ __forceinline__ void conv_gemm(const ConvArgs& a, const float* __rest
                 const bf16_t* Wl = reinterpret_cast<const bf16_t*>(a.wsc) + (size_t)(colbase + lrow) * 32 + kq * 8;
                 int abase[NMT > 0 ? NMT : 1];
 #pragma unroll
-                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + a.ntap] * rss + kq * 8;
+                for (int i = 0; i < NMT; ++i) abase[i] = tabL[trow[i] + a.ntap] * rss16 + kq * 8;
                 for (int ch = wk; ch < nch; ch += WK) {
                     u32x4 bf[NT];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) bf[t] = *reinterpret_cast<const u32x4*>(Wl + (size_t)ch * bstride + t * 512);
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) {
-                        const u32x4 af = afrag(XS + abase[i] + ch * 32);
+                        const u32x4 af = *reinterpret_cast<const u32x4*>(XS16 + abase[i] + ch * 32);
 #pragma unroll
                         for (int t = 0; t < NT; ++t) acc[i][t] = mfma16_bf16(af, bf[t], acc[i][t]);
                     }
@@ -356,9 +362,11 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
     const int tw = a.ntap + 1;
 
     // ---- stage 1: gather inputs, copy the tap table
-    conv_stage(X, rs, a.srcA, a.srcB, a.mapA, a.CA, a.CB, a.Cv, a.HWa, a.HWv, a.S, n0, a.NB, a.srcA_mod, tid, a.a_bf16, a.b_bf16);
+    // bf16 GEMM: inputs that need no GroupNorm are staged as bf16 straight away; a GroupNorm input is staged fp32 (statistics) and
+    // narrowed in place by the normalisation pass below
+    conv_stage(X, rs, a.srcA, a.srcB, a.mapA, a.CA, a.CB, a.Cv, a.HWa, a.HWv, a.S, n0, a.NB, a.srcA_mod, tid, a.a_bf16, a.b_bf16, BF16 && a.G == 0);
     if (a.Csc)
-        conv_stage(XS, rss, a.scA, a.scB, a.mapSc, a.CscA, a.CscB, a.Csc, a.HWsa, a.HWo, a.S, n0, a.NB, a.scA_mod, tid, a.a_bf16, a.b_bf16);
+        conv_stage(XS, rss, a.scA, a.scB, a.mapSc, a.CscA, a.CscB, a.Csc, a.HWsa, a.HWo, a.S, n0, a.NB, a.scA_mod, tid, a.a_bf16, a.b_bf16, BF16);
     for (int i = tid; i < a.Mpad * tw; i += RDMI_THREADS) tabL[i] = a.tab[i];
 
     // ---- stage 2: GroupNorm statistics (two-pass, in LDS) + affine + SiLU, in place
@@ -388,6 +396,41 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
             stat[2 * pair + 1] = 1.0f / sqrtf(sq * inv_cnt + a.eps);
         }
         __syncthreads();
+        if (BF16) {
+            // normalise + narrow IN PLACE: row p keeps its byte stride but ends up holding bf16 in its first Cv * 2 bytes.  A wave owns
+            // whole rows (64 / c4n of them per pass when c4n divides 64, else one), so no other wave touches a row it rewrites.
+            typedef unsigned int u32x2 __attribute__((vector_size(8)));
+            const int c4n = a.Cv >> 2;
+            const int rpw = (64 % c4n) == 0 ? 64 / c4n : 1;                 // rows per wave pass
+            const int rows = a.S * a.HWv;
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int r0 = wv * rpw; r0 < rows; r0 += 4 * rpw) {
+                for (int cb = 0; cb < (rpw > 1 ? 1 : (c4n + 63) / 64); ++cb) {
+                    const int rl = rpw > 1 ? ln / c4n : 0, c4 = rpw > 1 ? ln - rl * c4n : cb * 64 + ln;
+                    const int pv = r0 + rl;
+                    const bool on = pv < rows && c4 < c4n;
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                    const int c = c4 << 2;
+                    if (on) {
+                        const int ss = pv / a.HWv, v = pv - ss * a.HWv;
+                        val = *reinterpret_cast<const f32x4*>(X + (size_t)pv * rs + c);
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
+                        int gg = c / Cg, left = Cg - (c - gg * Cg);
+                        for (int j = 0; j < 4; ++j) {
+                            if (left == 0) { ++gg; left = Cg; }
+                            const float mu = stat[2 * (ss * G + gg)], rstd = stat[2 * (ss * G + gg) + 1];
+                            val[j] = silu_f((val[j] - mu) * rstd * gm[j] + bt[j]);
+                            if (a.drop_p > 0.f) val[j] *= dropout_scale(a.drop_seed, a.op_id, ((uint64_t)(n0 + ss) * a.HWv + v) * a.Cv + c + j, a.drop_p);
+                            --left;
+                        }
+                    }
+                    // every lane's fp32 read above precedes every lane's bf16 write below (a wave's LDS instructions execute in issue
+                    // order): the bf16 of channel quad c4 lands on bytes [8 c4, 8 c4 + 8) = fp32 quad c4 / 2 of the same row
+                    wave_order_point();
+                    if (on) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(X + (size_t)pv * rs) + c) = u32x2{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+                }
+            }
+        } else {
         // normalise: a work-item keeps its float4 channel column (fixed gamma/beta/group) and walks pixels
         const int c4n = a.Cv >> 2;
         const int total = a.S * a.HWv * c4n;
@@ -413,6 +456,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
             if (c4 >= c4n) { c4 -= c4n; ++pv; }
         }
     }
+        }
     __syncthreads();
 
     // ---- stage 3/4: GEMM + epilogue, specialised on this wave's (uniform) number of row tiles

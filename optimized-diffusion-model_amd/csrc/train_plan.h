@@ -116,7 +116,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             if (op.kind != OP_CONV) continue;
             ConvArgs& ca = op.conv;
             const ConvSpec& sp = op.spec;
-            if ((ca.Cv & 31) || (ca.Csc & 31)) continue;
+            if ((ca.Cv & 31) || (ca.Csc & 31) || ca.Cv > 256) continue;   // > 256 channels: the in-place narrowing of conv_mfma_kernel needs one pass per row
             const int Cin = sp.CA + sp.CB;
             {
                 PackJob j{};
@@ -224,7 +224,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
             j.dst = reinterpret_cast<float*>(b.wT_off);
             j.Cin = sp.Cout; j.Cout = Cin; j.Kpad = d.Cv; j.Npad = d.Cout_pad; j.n_off = 0; j.ntap = 9;
             j.s_co = 9; j.s_ci = (long)Cin * 9; j.s_t = 1; j.kind = 0;     // "co" of the job = ci of W, "ci" of the job = co of W
-            if (bf && (d.Cv & 31) == 0) { j.kind = 2; d.bf16 = 1; }
+            if (bf && (d.Cv & 31) == 0 && d.Cv <= 256) { j.kind = 2; d.bf16 = 1; }
             if (bf) { d.a_bf16 = 1; d.o_bf16 = 1; }
             T.jobs.push_back(j); T.job_param.push_back(b.p_w);
         }
