@@ -24,7 +24,7 @@ struct TConvArgs {
     int Hv, Wv;                             // virtual input grid (after upsampling)
     int stride, pad_lo, ntap;               // 3x3: (1, 1, 9) or Downsample's (2, 0, 9) with the implicit bottom/right zero; 1x1: (1, 0, 1)
     int Ho, Wo, TR;                         // output grid; output image rows per tile (TR * Wo = 64, or the whole 4x4 image)
-    const float* stats; int G, Cg;          // GroupNorm: [n][G][2] (mean, rstd) or null; Cg channels per group (multiple of 4)
+    const float* stats; int G, Cg;          // GroupNorm: [n][G][2] (mean, rstd) or null; Cg channels per group
     const float* gamma; const float* beta; int act;
     const float* wpk;                       // [ntap][Cv/16][Cout_pad][16]
     const float* bias;
@@ -99,12 +99,21 @@ template <bool BF16>
 __device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g, int n, int c0, int npix, int tid, const f32x4 (&raw)[TC_MAXS]) {
     const int Cin = a.CA + a.CB;
     const int q = tid & 7, c = c0 + q * 4;
-    float mean = 0.f, rstd = 1.f;
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};      // per channel of the quad: a group of 6 channels (C = 192) straddles quads
     f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
     const bool gn = a.stats != nullptr && c < Cin;
     if (gn) {
-        const int grp = c / a.Cg;
-        mean = a.stats[((size_t)n * a.G + grp) * 2]; rstd = a.stats[((size_t)n * a.G + grp) * 2 + 1];
+        if ((a.Cg & 3) == 0) {                                   // the usual case: one group per quad
+            const int grp = c / a.Cg;
+            const float m0 = a.stats[((size_t)n * a.G + grp) * 2], r0 = a.stats[((size_t)n * a.G + grp) * 2 + 1];
+            mean = f32x4{m0, m0, m0, m0}; rstd = f32x4{r0, r0, r0, r0};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int grp = min(c + j, Cin - 1) / a.Cg;
+                mean[j] = a.stats[((size_t)n * a.G + grp) * 2]; rstd[j] = a.stats[((size_t)n * a.G + grp) * 2 + 1];
+            }
+        }
         gm = *reinterpret_cast<const f32x4*>(a.gamma + c); bt = *reinterpret_cast<const f32x4*>(a.beta + c);
     }
 #pragma unroll
@@ -115,7 +124,7 @@ __device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g
         f32x4 v = raw[k];
         if (gn && g.sp[k] >= 0) {                           // padding stays zero: the conv pads the ACTIVATED tensor
             for (int j = 0; j < 4; ++j) {
-                const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
+                const float y = (v[j] - mean[j]) * (rstd[j] * gm[j]) + bt[j];
                 v[j] = a.act ? silu_f(y) : y;
             }
         }
@@ -275,11 +284,16 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < Cin) {
             v = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + (size_t)np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + (size_t)np * a.CB + (c - a.CA));
-            const int grp = c / a.Cg;
-            const float mean = a.stats[((size_t)n * a.G + grp) * 2], rstd = a.stats[((size_t)n * a.G + grp) * 2 + 1];
             const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
+            const int g0 = c / a.Cg;
+            const float m0 = a.stats[((size_t)n * a.G + g0) * 2], r0 = a.stats[((size_t)n * a.G + g0) * 2 + 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                float mean = m0, rstd = r0;
+                if (a.Cg & 3) {                                    // a group of 6 channels (C = 192) straddles quads: per-channel lookup
+                    const int grp = (c + j) / a.Cg;
+                    mean = a.stats[((size_t)n * a.G + grp) * 2]; rstd = a.stats[((size_t)n * a.G + grp) * 2 + 1];
+                }
                 const float y = (v[j] - mean) * (rstd * gm[j]) + bt[j];
                 v[j] = a.act ? silu_f(y) : y;
             }

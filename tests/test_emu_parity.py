@@ -490,16 +490,17 @@ def check_bf16_train(out, g):
 
 
 def _small_rgb_model(ge, compute_dtype):
-    """A 16x16 RGB NCSN++ (nf=32, ch_mult [1,2,2], one block per level, attention at 8x8, scale_by_sigma): small enough for the
+    """A 16x16 RGB NCSN++ (nf=64, ch_mult [1,2,2], one block per level, attention at 8x8 with C=128, scale_by_sigma: the bf16 plan's copy-staged
+    3x3 and 1x1 convs and fused attention core are reached, and the 192-channel concat has 6-channel GroupNorm groups): small enough for the
     emulator, and -- more than one image channel -- planned by the spatially TILED plan like BASELINE config #5."""
     from oracle.weights import make_params
     from rdmi.models import utils as mutils
     cfg = ge.demo_config(image_size=16, image_width=16)
     m = cfg.model
-    m.nf, m.ch_mult, m.num_res_blocks, m.attn_resolutions = 32, [1, 2, 2], 1, [8]
+    m.nf, m.ch_mult, m.num_res_blocks, m.attn_resolutions = 64, [1, 2, 2], 1, [8]
     m.channels, m.scale_by_sigma, m.compute_dtype = 3, True, compute_dtype
     cfg.sde.sigma_max = 50
-    params = make_params(3, nf=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16, channels=3)
+    params = make_params(3, nf=64, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16, channels=3)
     model = mutils.create_model(cfg)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
     return model.eval(), params
