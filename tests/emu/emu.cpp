@@ -41,7 +41,9 @@ struct Block {
 thread_local Lane* cur = nullptr;
 thread_local dim3 t_bid, t_bdim, t_gdim;
 static thread_local Block* blk = nullptr;
-static thread_local std::vector<unsigned char*>* stacks = nullptr;
+// fiber stacks of the calling thread, released when the (per-launch) worker thread ends
+struct StackPool { std::vector<unsigned char*> v; ~StackPool() { for (auto* p : v) std::free(p); } };
+static thread_local StackPool stack_pool;
 
 const dim3& cur_tid() { return cur->tid; }
 int lane_id() { return cur->linear & 63; }
@@ -103,7 +105,7 @@ static void run_block(void (*tramp)(void*), void* args, dim3 bid, dim3 grid, dim
     b.waves.resize((nt + 63) / 64);
     b.live = nt;
     b.tramp = tramp; b.args = args;
-    if (!stacks) stacks = new std::vector<unsigned char*>();
+    std::vector<unsigned char*>* stacks = &stack_pool.v;
     while ((int)stacks->size() < nt) stacks->push_back(static_cast<unsigned char*>(std::malloc(STACK)));
     for (int i = 0; i < nt; ++i) {
         Lane& l = b.lanes[i];
