@@ -138,6 +138,9 @@ __device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g
 }
 
 // Shared epilogue of the tiled convs: bias, Dense_0(temb) column add, residual, 1/sqrt2 (and 1/sigma), store, per-tile channel sums.
+// Per column tile the NMT * 4 residual loads are issued together BEFORE any store (with one load -> wait -> store chain per element
+// a workgroup spent 32 exposed memory latencies here: the ISA showed s_waitcnt vmcnt(0) after every load); invalid elements
+// (columns beyond Cout, rows beyond the tile / image) read offset 0 and are masked at the store.
 template <int NMT, int NCT>
 __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, const f32x4 (&acc)[NMT][NCT], int n, int tile, int tiles_per_img, int oy0, int col0, int kq) {
     float sdiv = 1.f;
@@ -147,32 +150,43 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, const f32x4 (
     }
     const float scale = a.out_scale / sdiv;
     const int HWo = a.Ho * a.Wo, tile_px = a.TR * a.Wo;
+    const size_t nbase = (size_t)n * HWo * a.Cout;             // wave-uniform sample base; element offsets below fit 32 bits
+    const float* rbase = a.resid ? a.resid + nbase : nullptr;
+    float* obase = a.out + nbase;
 #pragma unroll
     for (int cc = 0; cc < NCT; ++cc) {
         const int col = col0 + cc * 16;
-        if (col >= a.Cout) continue;
-        float add = a.bias ? a.bias[col] : 0.f;
-        if (a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
+        const bool colok = col < a.Cout;
+        float add = (colok && a.bias) ? a.bias[col] : 0.f;
+        if (colok && a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];
+        unsigned off[NMT][4]; bool ok[NMT][4]; float rv[NMT][4];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i * 16 + kq * 4 + r, opix = oy0 * a.Wo + m;
+                ok[i][r] = colok && m < tile_px && opix < HWo;
+                off[i][r] = ok[i][r] ? (unsigned)(opix * a.Cout + col) : 0u;
+                rv[i][r] = 0.f;
+            }
+        if (rbase) {
+#pragma unroll
+            for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rv[i][r] = rbase[off[i][r]];
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NMT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = i * 16 + kq * 4 + r;
-                const int opix = oy0 * a.Wo + m;
-                if (m < tile_px && opix < HWo) {
-                    const size_t o = ((size_t)n * HWo + opix) * a.Cout + col;
-                    float v = acc[i][cc][r] + add;
-                    if (a.resid) v += a.resid[o];
-                    v *= scale;
-                    a.out[o] = v;
-                    s1 += v; s2 += v * v;
-                }
+                const float v = (acc[i][cc][r] + add + rv[i][r]) * scale;
+                if (ok[i][r]) { obase[off[i][r]] = v; s1 += v; s2 += v * v; }
             }
         if (a.chsum) {            // this lane's column over its rows, then over the four k-groups that hold the other rows of the tile
             s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-            if (kq == 0) {        // every (sample, tile, column) has exactly one writer: no atomics, run-to-run identical
+            if (kq == 0 && colok) {   // every (sample, tile, column) has exactly one writer: no atomics, run-to-run identical
                 float* cs = a.chsum + (((size_t)n * tiles_per_img + tile) * a.Cout + col) * 2;
                 cs[0] = s1; cs[1] = s2;
             }
@@ -368,8 +382,8 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
             raw[k] = u32x4{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u};
         }
     };
-    // The (tap, k-step) MFMA groups of a slab are unrolled with the B fragments in a ring of three register sets loaded two
-    // groups ahead (the first two before the slab's window is committed), so the weight loads' L2 latency is covered by MFMA work;
+    // The (tap, k-step) MFMA groups of a slab are unrolled with the B fragments in a ring of register sets loaded several
+    // groups ahead (the first ones before the slab's window is committed), so the weight loads' L2 latency is covered by MFMA work;
     // sched_fence / opaque_sgpr keep the compiler from hoisting every group's loads and addresses (which spills).
     // Group j = (tap j / KSTEPS, k-step j % KSTEPS); k-steps beyond the tensor's channels (1x1 over fewer than 256) are skipped.
     auto loadB = [&](int j, int c0, u32x4 (&b)[NCT]) {
@@ -390,11 +404,15 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
             for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = mfma16_bf16(af, b[cc], acc[i][cc]);
         }
     };
+    // ring depth: the loads of group j + RING - 1 are issued before the MFMAs of group j (an L2 hit takes 500-800 cycles, a group
+    // of NMT * NCT MFMAs 128-256): deeper for the narrow column tiles, whose groups are short and whose fragments are few registers
+    constexpr int RING = NCT >= 4 ? 4 : 6, AHEAD = RING - 1;
     fetch(0);
     for (int c0 = 0; c0 < a.Cv; c0 += KS) {
-        u32x4 br[3][NCT];
-        loadB(0, c0, br[0]);
-        loadB(1, c0, br[1]);
+        u32x4 br[RING][NCT];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j)
+            if (j < GROUPS) loadB(j, c0, br[j]);
 #pragma unroll
         for (int k = 0; k < TC_MAXS; ++k) {
             const int i = tid + k * RDMI_THREADS;
@@ -405,8 +423,8 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
         const int ksteps = min(KSTEPS, nk - (c0 >> 5));
 #pragma unroll
         for (int j = 0; j < GROUPS; ++j) {
-            if (j + 2 < GROUPS) loadB(j + 2, c0, br[(j + 2) % 3]);
-            if (KSTEPS == 2 || (j % KSTEPS) < ksteps) mma(j, br[j % 3]);      // Cv % 64 == 0: a 64-channel slab is always whole
+            if (j + AHEAD < GROUPS) loadB(j + AHEAD, c0, br[(j + AHEAD) % RING]);
+            if (KSTEPS == 2 || (j % KSTEPS) < ksteps) mma(j, br[j % RING]);      // Cv % 64 == 0: a 64-channel slab is always whole
             sched_fence();
         }
         __syncthreads();
