@@ -32,12 +32,25 @@ __global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const fl
         const int r = tid / cw, c = c0 + tid - r * cw;
         float s = 0.f;
         if (r < R)
-            for (int p = r; p < HW; p += R) {
-                const size_t i = ((size_t)n * HW + p) * C + c;
-                const float g = gY[i] * scale;
-                stact1(G, i, g, g_bf16);
-                if (gR) gR[i] += g;
-                s += g;
+            for (int p0 = r; p0 < HW; p0 += 4 * R) {            // four pixels per pass: their loads are issued before any store
+                float gy[4], gr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u * R;
+                    const size_t i = ((size_t)n * HW + min(p, HW - 1)) * C + c;
+                    gy[u] = gY[i]; gr[u] = gR ? gR[i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u * R;
+                    if (p < HW) {
+                        const size_t i = ((size_t)n * HW + p) * C + c;
+                        const float g = gy[u] * scale;
+                        stact1(G, i, g, g_bf16);
+                        if (gR) gR[i] = gr[u] + g;
+                        s += g;
+                    }
+                }
             }
         red[tid] = r < R ? s : 0.f;
         __syncthreads();
@@ -164,22 +177,42 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
         }
     }
     __syncthreads();
-    // scatter GV (in Gt) to the sources' gradient accumulators
+    // scatter GV (in Gt) to the sources' gradient accumulators.  Four read-modify-writes per work-item are in flight at a time: the
+    // loads of a group are issued before its stores (one load -> add -> store chain per iteration exposes a memory latency each).
+    constexpr int SU = 4;
     if (a.gA) {
         float* ga = a.gA + (size_t)n * a.HWa * a.CA;
-        for (int i = tid; i < a.HWa * a.CA; i += GN_THREADS) {
-            const int sp = i / a.CA, c = i - sp * a.CA;
-            float acc = 0.f;
-            if (a.inv_start) { for (int k = a.inv_start[sp]; k < a.inv_start[sp + 1]; ++k) acc += Gt[(size_t)a.inv_list[k] * rs + c]; }
-            else acc = Gt[(size_t)sp * rs + c];
-            ga[i] += acc;
+        const int tot = a.HWa * a.CA;
+        for (int i0 = tid; i0 < tot; i0 += SU * GN_THREADS) {
+            float old[SU], acc[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int i = i0 + u * GN_THREADS; old[u] = i < tot ? ga[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + u * GN_THREADS;
+                acc[u] = 0.f;
+                if (i < tot) {
+                    const int sp = i / a.CA, c = i - sp * a.CA;
+                    if (a.inv_start) { for (int k = a.inv_start[sp]; k < a.inv_start[sp + 1]; ++k) acc[u] += Gt[(size_t)a.inv_list[k] * rs + c]; }
+                    else acc[u] = Gt[(size_t)sp * rs + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int i = i0 + u * GN_THREADS; if (i < tot) ga[i] = old[u] + acc[u]; }
         }
     }
     if (a.gB) {
         float* gb = a.gB + (size_t)n * a.HWv * a.CB;
-        for (int i = tid; i < a.HWv * a.CB; i += GN_THREADS) {
-            const int v = i / a.CB, c = i - v * a.CB;
-            gb[i] += Gt[(size_t)v * rs + a.CA + c];
+        const int tot = a.HWv * a.CB;
+        for (int i0 = tid; i0 < tot; i0 += SU * GN_THREADS) {
+            float old[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int i = i0 + u * GN_THREADS; old[u] = i < tot ? gb[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + u * GN_THREADS;
+                if (i < tot) { const int v = i / a.CB, c = i - v * a.CB; gb[i] = old[u] + Gt[(size_t)v * rs + a.CA + c]; }
+            }
         }
     }
 }
