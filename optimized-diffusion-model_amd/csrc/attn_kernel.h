@@ -202,12 +202,22 @@ __global__ __launch_bounds__(RDMI_THREADS) void attn_mfma_kernel(AttnArgs a) {
         }
         const float b = a.b3[col];
         float* og = a.io_bf16 ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)n * L * C) : a.out + (size_t)n * L * C;
+        // the residual loads of all row tiles are issued before the first store (a load -> wait -> store chain per element otherwise)
+        float xr[MTMAX][4];
+#pragma unroll
+        for (int i = 0; i < MTMAX; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(i * 16 + kq * 4 + r, L - 1);
+                xr[i][r] = ldact1(xg, (size_t)row * C + col, a.io_bf16);
+            }
 #pragma unroll
         for (int i = 0; i < MTMAX; ++i)
             if (i < mtiles)
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i * 16 + kq * 4 + r;
-                    if (row < L) stact1(og, (size_t)row * C + col, (ldact1(xg, (size_t)row * C + col, a.io_bf16) + acc[i][r] + b) * a.out_scale, a.io_bf16);
+                    if (row < L) stact1(og, (size_t)row * C + col, (xr[i][r] + acc[i][r] + b) * a.out_scale, a.io_bf16);
                 }
     }
 }

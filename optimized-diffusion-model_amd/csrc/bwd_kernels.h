@@ -783,9 +783,21 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(AttnBwdArgs a) {
             const int g = lane / Cg;
             const float rs = stat[4 * g + 1], m1 = stat[4 * g + 2] / cnt, m2 = stat[4 * g + 3] / cnt;
             float* gxo = a.gX + (size_t)n * L * C;
-            for (int p = wave; p < L; p += NW) {
-                const float gxh = V[p * LD + lane] * gam[lane];
-                gxo[p * C + lane] += rs * (gxh - m1 - P[p * LD + lane] * m2) + ldg1(gog + p * C + lane) * a.out_scale;
+            for (int p0 = wave; p0 < L; p0 += 4 * NW) {           // four rows per pass: the accumulator / gradient loads before the stores
+                float old[4], go[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = min(p0 + u * NW, L - 1);
+                    old[u] = gxo[p * C + lane]; go[u] = ldg1(gog + p * C + lane);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + u * NW;
+                    if (p < L) {
+                        const float gxh = V[p * LD + lane] * gam[lane];
+                        gxo[p * C + lane] = old[u] + (rs * (gxh - m1 - P[p * LD + lane] * m2) + go[u] * a.out_scale);
+                    }
+                }
             }
         }
         __syncthreads();
