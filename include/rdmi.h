@@ -230,6 +230,18 @@ const char* rdmi_path_info(rdmi_ctx* ctx);
  * during the last forward, with a one-line description per op.  Returns the op count. */
 int rdmi_debug_op_cycles(rdmi_ctx* ctx, long long* host_cycles, int cap, const char** desc, int desc_cap);
 
+/* Diagnostic: has any co-operative launch of this context (groups of four workgroups sharing the low-resolution section of the
+ * fused U-Net: DESIGN.md 4.2d) given up one of its bounded inter-workgroup waits?  *gave_up = 0: never; 1: yes -- the output
+ * samples of the affected workgroups were overwritten with NaN by the kernel itself.  Synchronises the device. */
+int rdmi_coop_status(rdmi_ctx* ctx, int* gave_up);
+
+/* Diagnostic: the N(0,1) draws the fused sampler makes when rdmi_pc_sample is called with noise == NULL
+ * (replaces torch.randn_like at RD/sampling.py:200,224): z[i], i < n, = Philox4x32-10 + Box-Muller value of global element
+ * elem_offset + i of noise tensor number `draw` under `seed` -- rdmi_pc_sample uses elem_offset = seq_offset * H*W*C + b * H*W*C + e
+ * and numbers the noise tensors 0, 1, ... in the order the reference would draw them.  Lets tests check the stream's
+ * distribution and feed the very same values to the oracle. */
+int rdmi_philox_normal(float* z, size_t n, unsigned long long seed, unsigned long long elem_offset, unsigned draw, void* stream);
+
 const char* rdmi_last_error(void);
 const char* rdmi_version(void);
 

@@ -198,6 +198,44 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) {
 #endif
 }
 
+// ---- inter-workgroup exchange slots (co-operative U-Net program): 16-byte pairs of 8-byte {value, tag} granules, written and read
+// with device-scope (sc1) buffer accesses: the store is write-through, the load bypasses this CU's L1 -- the data IS the flag
+// (MI355X_MICROARCH.md "visibility", form R2: no fence, no separate flag, placement-independent).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned int xq_t __attribute__((ext_vector_type(4)));
+struct XBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ XBuf xbuf_make(unsigned long long* p, unsigned bytes) { return XBuf{__builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000)}; }
+__device__ __forceinline__ void xbuf_store16(const XBuf& b, unsigned off, unsigned v0, unsigned v1, unsigned tag) {
+    __builtin_amdgcn_raw_buffer_store_b128(xq_t{v0, tag, v1, tag}, b.r, (int)off, 0, 16);      // aux 16 = sc1
+}
+__device__ __forceinline__ u32x4 xbuf_load16(const XBuf& b, unsigned off) {
+    const xq_t q = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)off, 0, 16);
+    return u32x4{q[0], q[1], q[2], q[3]};
+}
+__device__ __forceinline__ void spin_relax() { __builtin_amdgcn_s_sleep(1); }
+#define RDMI_SPIN_LIMIT (1ull << 21)
+#elif defined(RDMI_EMU)
+struct XBuf { unsigned long long* p; };
+__device__ __forceinline__ XBuf xbuf_make(unsigned long long* p, unsigned) { return XBuf{p}; }
+__device__ __forceinline__ void xbuf_store16(const XBuf& b, unsigned off, unsigned v0, unsigned v1, unsigned tag) {
+    __atomic_store_n(b.p + (off >> 3), ((unsigned long long)tag << 32) | v0, __ATOMIC_RELEASE);
+    __atomic_store_n(b.p + (off >> 3) + 1, ((unsigned long long)tag << 32) | v1, __ATOMIC_RELEASE);
+}
+__device__ __forceinline__ u32x4 xbuf_load16(const XBuf& b, unsigned off) {
+    const unsigned long long a = __atomic_load_n(b.p + (off >> 3), __ATOMIC_ACQUIRE), c = __atomic_load_n(b.p + (off >> 3) + 1, __ATOMIC_ACQUIRE);
+    return u32x4{(unsigned)a, (unsigned)(a >> 32), (unsigned)c, (unsigned)(c >> 32)};
+}
+__device__ __forceinline__ void spin_relax() { emu::relax(); }
+#define RDMI_SPIN_LIMIT (1ull << 40)
+#else
+struct XBuf { unsigned long long* p; };
+__device__ __forceinline__ XBuf xbuf_make(unsigned long long* p, unsigned) { return XBuf{p}; }
+__device__ __forceinline__ void xbuf_store16(const XBuf&, unsigned, unsigned, unsigned, unsigned) { abort(); }      // host pass of hipcc: never executed
+__device__ __forceinline__ u32x4 xbuf_load16(const XBuf&, unsigned) { abort(); return u32x4{0, 0, 0, 0}; }
+__device__ __forceinline__ void spin_relax() {}
+#define RDMI_SPIN_LIMIT (1ull << 21)
+#endif
+
 // Keep a value alive without using it (for L2-warming touches): the wait for the load lands where this is placed.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RDMI_KEEP(x) asm volatile("" ::"v"(x))

@@ -159,6 +159,7 @@ struct rdmi_ctx {
         std::vector<FOp> fprog; std::vector<FPatch> fpatch; std::vector<short> ftabs; std::vector<std::string> fdesc;
         FOp* d_fprog = nullptr; short* d_ftabs = nullptr; float* d_spill = nullptr; size_t spill_per_sample = 0;
         UnetArgs fargs{}; size_t fused_lds = 0;
+        bool coop = false; int n_xchg = 0; unsigned long long* d_xbuf = nullptr; int* d_coop_err = nullptr; int max_nb = 0;     // co-operative program
     };
     // tiled plan (shapes whose samples do not fit one workgroup: csrc/tiled_kernels.h)
     struct TLaunch {
@@ -187,12 +188,21 @@ struct rdmi_ctx {
     float *t_ws = nullptr, *t_xin = nullptr, *t_out = nullptr; size_t t_ws_per_sample = 0;
     std::vector<FusedProg> progs;
     int s_min_wg = 256;                            // a program with S samples per workgroup is used from batch s_min_wg * S (RDMI_S_MIN_WG: tests)
-    const FusedProg* pick(int NB) const {          // the program with the most samples per workgroup that still fills the chip
+    bool use_coop = true;                          // RDMI_COOP=0: never select the co-operative program (A/B, tests)
+    int coop_stride = 8;                           // ids of a group's members are this far apart (8: one XCD under round-robin placement; RDMI_COOP_STRIDE)
+    unsigned coop_epoch = 0;                       // tag base of the next co-operative launch
+    int last_prog = 0;                             // index in progs of the program the last forward ran (diagnostics)
+    const FusedProg* pick(int NB) const {
+        // a batch that leaves CUs to spare at one sample per workgroup and fits the chip in ONE wave of workgroups: the co-operative
+        // program (groups of four CUs share the low-resolution weights); larger batches: the program with the most samples per
+        // workgroup that still fills the chip
+        if (use_coop) for (auto& q : progs) if (q.ok && q.coop && NB <= q.max_nb) return &q;
         const FusedProg* best = nullptr;
-        for (auto& q : progs) if (q.ok && (q.S == 1 || NB >= s_min_wg * q.S) && (!best || q.S > best->S)) best = &q;
+        for (auto& q : progs) if (q.ok && !q.coop && (q.S == 1 || NB >= s_min_wg * q.S) && (!best || q.S > best->S)) best = &q;
         return best;
     }
     bool fused_ready() const { return !progs.empty() && progs[0].ok; }
+    int cur_coop = 0, cur_nxchg = 0, cur_cap_n = 0; unsigned long long* cur_xbuf = nullptr; int* cur_coop_err = nullptr;      // construction state (see stash_program)
     std::map<std::string, size_t> wmap;  // packed-weight arena offsets by parameter prefix
     bool packed_valid = false;
     bool debug_taps = false;
@@ -992,6 +1002,10 @@ struct FusedBuilder {
     int tab1_lds = 0;                          // LDS byte offset of region 1 (an arena block of the low-resolution section)
     struct LT { int off = -1, C = 0, H = 0, W = 0, rs = 0, bytes = 0, ns = 1; int hw() const { return H * W; } int rows() const { return ns * H * W; } };
     int S = 1;                      // samples per workgroup of the program being built
+    bool coop = false;              // co-operative program: S = 4 samples per GROUP of four workgroups (unet_kernel.h: fop_conv_coop)
+    int n_xchg = 0;                 // exchanges emitted so far
+    int xslot_granules = 0;         // largest exchanged block, in 8-byte granules
+    struct PendX { bool on = false; LT t; } pendx;      // output of the last co-operative 3x3 conv: exchanged before the next op is emitted
     int cur_samp = 0;               // sample slot the emitted ops belong to; -1: ops cover all S samples (low-resolution section)
     int multi_slot_off = -1;        // LDS offset of the per-(sample, group) partial-sum slots of multi-sample fused GroupNorms
     int ns_now() const { return cur_samp < 0 ? S : 1; }
@@ -1107,7 +1121,23 @@ struct FusedBuilder {
         o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1; o.gn_off = -1; o.samp = cur_samp;
         return o;
     }
-    int emit(const FOp& o) { c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
+    int emit(const FOp& o) { flush_xchg(); c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
+    // all-gather of tensor t (column slices of 32 per member) between the four members; t2: a second tensor of the same shape
+    int emit_xchg(const LT& t, const LT* own_rows_src) {
+        FOp o = blank(FOP_XCHG);
+        o.dst_off = t.off; o.dst_rs = t.rs; o.xidx = n_xchg++;
+        if (own_rows_src) {          // row slices: every member contributes its sample's rows (all columns)
+            o.a_hw = 1; o.rows = own_rows_src->hw(); o.C = t.C; o.a_off = own_rows_src->off; o.a_rs = own_rows_src->rs;
+            if (own_rows_src->C != t.C || t.rows() != 4 * o.rows) fail_("exchange: row-slice shapes");
+        } else {
+            o.a_hw = 0; o.rows = t.rows(); o.C = t.C / 4;
+        }
+        if (o.C < 32 || o.C > 128 || (o.C & (o.C - 1)) || o.rows * o.C > 2048) fail_("exchange: block of " + std::to_string(o.rows) + " x " + std::to_string(o.C));
+        xslot_granules = std::max(xslot_granules, 2 * o.rows * o.C);      // room for a second tensor
+        c->fprog.push_back(o);
+        return (int)c->fprog.size() - 1;
+    }
+    void flush_xchg() { if (pendx.on) { pendx.on = false; emit_xchg(pendx.t, nullptr); } }
     enum { F_GAMMA, F_BETA, F_BIAS, F_BIAS2, F_W, F_SC0W, F_SC1W, F_BIAS_ARENA };
     void patch_param(int op, int field, const std::string& param) { c->fpatch.push_back({op, field, param, 0}); }
     void patch_arena(int op, int field, size_t off) { c->fpatch.push_back({op, field, "", off}); }
@@ -1163,10 +1193,11 @@ struct FusedBuilder {
     bool try_fuse_gn(const LT& t, const std::string& pre, bool act, const LT* src) {
         if (!gn_fuse) return false;
         const LT& in = src ? *src : t;
-        int j = (int)c->fprog.size() - 1;
-        while (j >= 0 && c->fprog[(size_t)j].kind == FOP_STORE) --j;
+        int j = (int)c->fprog.size() - 1, jx = -1;
+        while (j >= 0 && (c->fprog[(size_t)j].kind == FOP_STORE || c->fprog[(size_t)j].kind == FOP_XCHG)) { if (c->fprog[(size_t)j].kind == FOP_XCHG) jx = j; --j; }
         if (j < 0) return false;
         FOp& p = c->fprog[(size_t)j];
+        if (p.coop && !pendx.on && (jx < 0 || c->fprog[(size_t)jx].dst_off != in.off || c->fprog[(size_t)jx].src_off >= 0)) return false;
         if (p.kind != FOP_CONV || p.dst_kind != 0 || p.gn_off >= 0 || p.dst_off != in.off || p.dst_rs != in.rs) return false;
         if (p.Cout != t.C || p.rows != t.rows() || t.C % 4 != 0 || std::min(t.C / 4, 32) * 4 != t.C) return false;      // Cg == 4 only
         const int ntiles = p.Cout_pad >> 4;
@@ -1181,6 +1212,12 @@ struct FusedBuilder {
         p.eps = 1e-6f; p.inv_cnt = 1.0f / (float)(4 * t.hw());
         patch_param(j, F_GAMMA, pre + ".weight"); patch_param(j, F_BETA, pre + ".bias");
         ++n_gn_fused;
+        if (p.coop) {        // the conv now also produces the activated tensor (own columns): it has to travel too
+            if (pendx.on) {
+                if (src) { pendx.on = false; const int ix = emit_xchg(in, nullptr); c->fprog[(size_t)ix].src_off = t.off; c->fprog[(size_t)ix].src_rs = t.rs; }
+                // in-place form: the pending exchange of the conv's destination already carries the activated values
+            } else if (src) { c->fprog[(size_t)jx].src_off = t.off; c->fprog[(size_t)jx].src_rs = t.rs; }
+        }
         return true;
     }
     void gn(const LT& t, const std::string& pre, bool act, const LT* src = nullptr) {
@@ -1191,12 +1228,15 @@ struct FusedBuilder {
         o.dst_off = t.off; o.dst_rs = t.rs; o.rows = t.rows(); o.C = t.C;
         o.G = std::min(t.C / 4, 32); o.act = act ? 1 : 0; o.eps = 1e-6f; o.hw_shift = shift_of(t.hw());
         {
-            const int T = UW_THREADS / o.G, c4n = t.C / 4;
-            o.logT = T == 32 ? 5 : (T == 16 ? 4 : (T == 64 ? 6 : 3));
+            // multi-sample ops spread the ns * G (sample, group) pairs over the workgroup: T lanes per pair
+            const int pairs = t.ns * o.G, T = UW_THREADS / pairs, c4n = t.C / 4;
+            o.logT = T == 32 ? 5 : (T == 16 ? 4 : (T == 64 ? 6 : (T == 8 ? 3 : 2)));
+            o.logG = 0; while ((1 << o.logG) < o.G) ++o.logG;
             o.Cg = t.C / o.G;
             o.magic_c4n = (65536 + c4n - 1) / c4n; o.magic_Cg = (65536 + o.Cg - 1) / o.Cg;
             o.inv_cnt = 1.0f / (float)(o.Cg * t.hw());
-            if ((1 << o.logT) != T) fail_("GroupNorm lanes-per-group not a power of two");
+            if ((1 << o.logT) != T || T * pairs != UW_THREADS) fail_("GroupNorm lanes-per-group not a power of two");
+            if ((1 << o.logG) != o.G) fail_("GroupNorm group count not a power of two");
             if (t.ns * o.G * 8 > 1024) fail_("GroupNorm statistics of all samples exceed the scratch region");
             if (ceil_div(t.hw(), T) > 6 || o.Cg > 8) fail_("GroupNorm group too large for the register-resident statistics");
         }
@@ -1232,6 +1272,13 @@ struct FusedBuilder {
         patch_arena(idx, F_W, c->wmap.at(wkey) + w_extra_off);
         if (!bias_param.empty()) patch_param(idx, F_BIAS, bias_param); else patch_arena(idx, F_BIAS_ARENA, bias_arena);
         if (sc_src) { patch_arena(idx, F_SC0W, c->wmap.at(sc_key)); patch_param(idx, F_BIAS2, bias2_param); }
+        if (coop && cur_samp < 0) {      // low-resolution section of the co-operative program: column-sliced, K split over the waves
+            FOp& q = c->fprog[(size_t)idx];
+            q.coop = 1;
+            if (q.Cout_pad != 128 || (q.mtiles != 1 && q.mtiles != 4) || q.main_ph.nch % 4 != 0 || dst_kind != 0 || !dst || dst->C != 128)
+                fail_("co-operative conv shape (Cout " + std::to_string(Cout) + ", " + std::to_string(q.mtiles) + " row tiles, " + std::to_string(q.main_ph.nch) + " chunks)");
+            if (ntap == 9) { pendx.on = true; pendx.t = *dst; }      // the next conv contracts over this tensor: all-gather it
+        }
         return idx;
     }
 };
@@ -1309,7 +1356,7 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
     return out;
 }
 
-int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used);
+int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used, bool coop);
 
 // A built program is moved out of the context's construction fields into one of these (one per samples-per-workgroup value).
 void stash_program(rdmi_ctx* c, int S) {
@@ -1318,21 +1365,34 @@ void stash_program(rdmi_ctx* c, int S) {
     q.fprog.swap(c->fprog); q.fpatch.swap(c->fpatch); q.ftabs.swap(c->ftabs); q.fdesc.swap(c->fdesc);
     q.d_fprog = c->d_fprog; q.d_ftabs = c->d_ftabs; q.d_spill = c->d_spill; q.spill_per_sample = c->spill_per_sample;
     q.fargs = c->fargs; q.fused_lds = c->fused_lds;
+    q.coop = c->cur_coop != 0; q.n_xchg = c->cur_nxchg; q.d_xbuf = c->cur_xbuf; q.d_coop_err = c->cur_coop_err; q.max_nb = c->cur_cap_n;
+    c->cur_coop = 0; c->cur_nxchg = 0; c->cur_xbuf = nullptr; c->cur_coop_err = nullptr; c->cur_cap_n = 0;
     c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr; c->spill_per_sample = 0; c->fused_ok = false; c->fused_why.clear();
     c->progs.push_back(std::move(q));
 }
 
-int build_one_program(rdmi_ctx* c, int S) {
+int build_one_program(rdmi_ctx* c, int S, bool coop = false) {
     int used = 0, used1 = 0;
-    if (int e = build_fused_program_pass(c, S, 8 * 1024, 24 * 1024, &used, &used1)) return e;
+    if (int e = build_fused_program_pass(c, S, 8 * 1024, 24 * 1024, &used, &used1, coop)) return e;
     if (c->fused_ok) {   // second pass with the table region sized exactly
-        for (void* p : {(void*)c->d_fprog, (void*)c->d_ftabs, (void*)c->d_spill}) if (p) (void)hipFree(p);
-        c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr;
+        for (void* p : {(void*)c->d_fprog, (void*)c->d_ftabs, (void*)c->d_spill, (void*)c->cur_xbuf, (void*)c->cur_coop_err}) if (p) (void)hipFree(p);
+        c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr; c->cur_xbuf = nullptr; c->cur_coop_err = nullptr;
     }
     c->fused_ok = false; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); c->fused_why.clear();
-    if (int e = build_fused_program_pass(c, S, (used + 63) & ~63, (used1 + 63) & ~63, &used, &used1)) return e;
+    if (int e = build_fused_program_pass(c, S, (used + 63) & ~63, (used1 + 63) & ~63, &used, &used1, coop)) return e;
     stash_program(c, S);
     return 0;
+}
+
+// How many workgroups of the fused kernel the device holds at once (one per CU: each takes the CU's whole LDS).
+int resident_workgroups() {
+#ifdef RDMI_EMU
+    return 256;
+#else
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+#endif
 }
 
 int build_fused_program(rdmi_ctx* c) {
@@ -1345,14 +1405,24 @@ int build_fused_program(rdmi_ctx* c) {
     for (int S : {2, 4})
         if (c->progs[0].ok && c->arch.n_levels >= 2 && c->max_batch >= c->s_min_wg * S && (!only || atoi(only) >= S))
             if (int e = build_one_program(c, S)) return e;
+    // The co-operative program (groups of four workgroups share the low-resolution section): for batches that fit the chip in one
+    // wave of workgroups.  RDMI_COOP=0 leaves it out; RDMI_COOP_STRIDE sets the distance between a group's workgroup ids.
+    if (const char* e = std::getenv("RDMI_COOP")) c->use_coop = atoi(e) != 0;
+#ifdef RDMI_EMU
+    c->coop_stride = 1;          // the emulator runs consecutive workgroup ids concurrently
+#endif
+    if (const char* e = std::getenv("RDMI_COOP_STRIDE")) c->coop_stride = std::max(1, atoi(e));
+    if (c->progs[0].ok && c->use_coop && c->arch.n_levels >= 2 && !only)
+        if (int e = build_one_program(c, 4, true)) return e;
     return 0;
 }
 
-int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used) {
+int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used, bool coop) {
     using LT = FusedBuilder::LT;
     const rdmi_arch& a = c->arch;
     FusedBuilder b{c};
-    b.S = S;
+    b.S = S; b.coop = coop;
+    const int nslot0 = coop ? 1 : S;                  // how often the full-resolution sections are emitted (co-operative: the member's own sample only)
     Layout L = build_layout(c);
     std::map<std::string, int> dense_off;
     {
@@ -1380,7 +1450,7 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
     LT h;
     // ---- level 0, down path: once per sample slot (same LDS, same spill slots)
     const int nrb = a.num_res_blocks;
-    for (int sl = 0; sl < S; ++sl) {
+    for (int sl = 0; sl < nslot0; ++sl) {
         b.cur_samp = sl;
         b.slot_replay = sl > 0; b.slot_pos = 0;
         H = H0; W = W0; ch = a.nf;
@@ -1406,25 +1476,60 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
             b.conv(h, H, W, Ho, Wo, 2, 0, 9, nm, 0, ch, nm + ".bias", 0, 0, &o, 1.f, -1, nullptr, nullptr, "", "");
             b.tfree(h);
             h = o; H = Ho; W = Wo;
-            if (multi) { hand_down = b.spill_store(h); b.tfree(h); }
+            if (multi && !coop) { hand_down = b.spill_store(h); b.tfree(h); }
         }
     }
     b.slot_replay = false;
-    // ---- levels >= 1 (down), bottleneck, levels >= 1 (up): all S samples at once when S > 1
+    // ---- levels >= 1 (down), bottleneck, levels >= 1 (up): all S samples at once when S > 1.
+    //      Co-operative program: only the levels of at most 4 pixels per sample (and the bottleneck) run in the shared form -- that
+    //      part is bound by the weight stream and by 4-row MFMA tiles with one sample per CU; the 4x4 level is matrix-pipe bound
+    //      either way (measured: sharing it costs more in exchanges than it saves) and stays per sample like level 0.
     int d = nrb, u = 0, loadtab_idx = -1;
     {
-        b.cur_samp = multi ? -1 : 0;
+        b.cur_samp = (multi && !coop) ? -1 : 0;
         int loadtab_op = -1;
-        if (multi) {
+        bool in_coop = false;
+        auto enter_multi = [&]() {
             b.multi_slot_off = b.alloc_top(4096);
             b.tab1_lds = b.alloc_top(TAB1_RESERVE);
             FOp lt = b.blank(FOP_LOADTAB);            // the section's row tables: global -> LDS (source / size patched below)
             lt.dst_off = b.tab1_lds;
             loadtab_op = b.emit(lt);
+        };
+        auto leave_multi = [&]() {
+            b.free_bytes(b.multi_slot_off, 4096);
+            b.multi_slot_off = -1;
+            b.free_bytes(b.tab1_lds, TAB1_RESERVE);
+            while (b.tabs1.size() % 8) b.tabs1.push_back(-1);
+            c->fprog[(size_t)loadtab_op].rows = (int)b.tabs1.size() * 2;      // bytes
+        };
+        auto enter_coop = [&]() {                     // h: this member's own sample -> the four samples of the group (rows of sample m come from member m)
+            b.flush_xchg();
+            b.cur_samp = -1;
+            enter_multi();
+            LT h4 = b.talloc(ch, H, W);
+            b.emit_xchg(h4, &h);
+            b.tfree(h);
+            h = h4; in_coop = true;
+        };
+        auto leave_coop = [&]() {                     // back to the member's own sample: its rows of the complete four-sample tensor
+            b.flush_xchg();
+            b.cur_samp = 0;
+            LT own = b.talloc(ch, H, W);
+            b.copy_t(own, h);
+            c->fprog.back().a_hw = own.hw(); c->fprog.back().a_mstride = own.hw() * h.rs * 4;
+            b.tfree(h);
+            h = own; in_coop = false;
+            leave_multi();
+        };
+        if (multi && !coop) {
+            enter_multi();
             h = b.talloc(ch, H, W);
             b.gather_g(h, hand_down);
         }
+        int coop_level = -1;
         for (int i = 1; i < nlev; ++i) {
+            if (coop && !in_coop && H * W <= 4) { enter_coop(); coop_level = i; }
             for (int j = 0; j < nrb; ++j, ++d) {
                 const BlockSpec& bs = L.down[(size_t)d];
                 h = fused_resblock(b, bs.name, h, bs.cout, dense_off[bs.name]);
@@ -1442,6 +1547,7 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
                 h = o; H = Ho; W = Wo;
             }
         }
+        if (coop && !in_coop) b.fail_("no level of at most 4 pixels per sample: nothing to share");
         h = fused_resblock(b, "mid_block1", h, ch, dense_off["mid_block1"]);
         h = fused_resblock(b, "mid_block2", h, ch, dense_off["mid_block2"]);
         for (int k = 0; k < nlev - 1; ++k) {          // up levels nlev-1 .. 1
@@ -1457,6 +1563,7 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
                 ch = bs.cout;
                 if (bs.attn) h = fused_attn(b, "up_attn." + std::to_string(u), h);
             }
+            if (in_coop && nlev - 1 - k == coop_level) leave_coop();      // the levels above run per sample again
             if (k != nlev - 2) {                       // upsample between two low levels stays in this section
                 LT o = b.talloc(ch, 2 * H, 2 * W);
                 const std::string nm = "upsample." + std::to_string(k) + ".Conv_0";
@@ -1465,24 +1572,20 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
                 h = o; H *= 2; W *= 2;
             }
         }
-        if (multi) {
-            hand_up = b.spill_store(h);
-            b.tfree(h);
-            b.free_bytes(b.multi_slot_off, 4096);
-            b.multi_slot_off = -1;
-            b.free_bytes(b.tab1_lds, TAB1_RESERVE);
-            while (b.tabs1.size() % 8) b.tabs1.push_back(-1);
-            c->fprog[(size_t)loadtab_op].rows = (int)b.tabs1.size() * 2;      // bytes
+        if (in_coop) leave_coop();
+        if (multi && !coop) {
+            hand_up = b.spill_store(h); b.tfree(h);
+            leave_multi();
         }
         loadtab_idx = loadtab_op;
     }
     // ---- level 0, up path: once per sample slot
     const int u0 = u, ch_low = ch, H_low = H, W_low = W;
     const std::vector<HS> hs0 = hs;
-    for (int sl = 0; sl < S; ++sl) {
+    for (int sl = 0; sl < nslot0; ++sl) {
         b.cur_samp = sl;
         u = u0; ch = ch_low; H = H_low; W = W_low; hs = hs0;
-        if (multi) { h = b.talloc(ch, H, W); b.gather_g(h, hand_up); }
+        if (multi && !coop) { h = b.talloc(ch, H, W); b.gather_g(h, hand_up); }
         if (nlev > 1) {                                // the upsample conv onto level 0's (even) grid
             LT o = b.talloc(ch, 2 * H, 2 * W);
             const std::string nm = "upsample." + std::to_string(nlev - 2) + ".Conv_0";
@@ -1532,14 +1635,26 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
     const size_t tab0_shorts = c->ftabs.size();                  // region 0 is what the kernel copies at start; region 1 follows it in the buffer
     c->ftabs.insert(c->ftabs.end(), b.tabs1.begin(), b.tabs1.end());
     c->spill_per_sample = b.spill_floats;
-    HIP_OK(hipMalloc((void**)&c->d_spill, std::max<size_t>(c->spill_per_sample, 1) * (size_t)c->max_batch * sizeof(float)));
+    // spill slots are [slot][n][rows][C].  Co-operative program: the low-resolution slots are indexed by (workgroup, sample of its group),
+    // n = 4 * workgroup id + slot, so the buffer holds 4 * (largest grid) "samples" per slot
+    int coop_max_nb = 0, spill_n = c->max_batch;
+    if (coop) {
+        const int st = c->coop_stride, res = resident_workgroups();
+        const int max_groups = (res / (4 * st)) * st;                      // whole blocks of 4 * stride workgroup ids that are resident together
+        coop_max_nb = std::min(c->max_batch, 4 * max_groups);
+        if (coop_max_nb < 1) b.fail_("no room for one co-operative group");
+        const int grid_max = ceil_div(ceil_div(std::max(coop_max_nb, 1), 4), st) * 4 * st;
+        spill_n = 4 * grid_max;
+    }
+    if (b.failed) { c->fused_why = b.why; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); return 0; }
+    HIP_OK(hipMalloc((void**)&c->d_spill, std::max<size_t>(c->spill_per_sample, 1) * (size_t)spill_n * sizeof(float)));
     HIP_OK(hipMalloc((void**)&c->d_fprog, c->fprog.size() * sizeof(FOp)));
     HIP_OK(hipMalloc((void**)&c->d_ftabs, c->ftabs.size() * sizeof(short)));
     HIP_OK(hipMemcpy(c->d_ftabs, c->ftabs.data(), c->ftabs.size() * sizeof(short), hipMemcpyHostToDevice));
     // spill slots: [slot][n][rows][C] so a workgroup only ever touches its own sample's rows
     for (auto& f : b.spill_fix) {
         FOp& o = c->fprog[(size_t)f.op];
-        float* p = c->d_spill + f.off * (size_t)c->max_batch;
+        float* p = c->d_spill + f.off * (size_t)spill_n;
         if (f.which == 1) o.b_g = p; else if (f.which == 2) o.a_g = p; else o.g_out = p;
     }
     c->fargs = UnetArgs{};
@@ -1548,14 +1663,30 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
     if (loadtab_idx >= 0) c->fprog[(size_t)loadtab_idx].a_g = reinterpret_cast<const float*>(c->d_ftabs + tab0_shorts);
     c->fargs.zero_off = TAB_RESERVE; c->fargs.zero_bytes = zero_bytes;
     c->fargs.dense = c->d_dense; c->fargs.dense_stride = c->dense_total; c->fargs.S = S;
+    c->fargs.out_elems = c->H * c->W * a.channels;
+    if (coop) {
+        const int groups_max = ceil_div(coop_max_nb, 4);
+        const size_t xb = (size_t)groups_max * 2 * 4 * (size_t)b.xslot_granules * sizeof(unsigned long long);
+        HIP_OK(hipMalloc((void**)&c->cur_xbuf, std::max<size_t>(xb, 16)));
+        HIP_OK(hipMemset(c->cur_xbuf, 0, std::max<size_t>(xb, 16)));          // tags start at 0; epochs never are
+        HIP_OK(hipMalloc((void**)&c->cur_coop_err, 16));
+        HIP_OK(hipMemset(c->cur_coop_err, 0, 16));
+        c->fargs.coop = 1; c->fargs.coop_stride = c->coop_stride; c->fargs.xbuf = c->cur_xbuf; c->fargs.xslot = b.xslot_granules;
+        c->fargs.coop_err = c->cur_coop_err;
+        c->cur_coop = 1; c->cur_nxchg = b.n_xchg; c->cur_cap_n = coop_max_nb;
+    }
     c->fused_lds = (size_t)b.high_water;
     if (const char* e = std::getenv("RDMI_UDBG")) c->fargs.dbg = atoi(e);
-    if (std::getenv("RDMI_STAMPS") && S == 1 && !c->d_stamps) { HIP_OK(hipMalloc((void**)&c->d_stamps, (1024 + c->fprog.size() * 8 + 8) * sizeof(long long))); c->fargs.stamps = c->d_stamps; }
+    if (std::getenv("RDMI_STAMPS") && (S == 1 || coop)) {       // diagnostic builds exist for the single-sample and the co-operative program
+        if (!c->d_stamps) HIP_OK(hipMalloc((void**)&c->d_stamps, (1024 + 200 * 8 + 8) * sizeof(long long)));
+        if (c->fprog.size() > 200) return fail("RDMI_STAMPS: program of %zu ops", c->fprog.size());
+        c->fargs.stamps = c->d_stamps;
+    }
     c->fdesc.clear();
     for (auto& o : c->fprog) {
         char buf[160];
-        const char* kn[] = {"GATHER", "STORE", "GN", "CONV", "ATTN", "LOADTAB"};
-        if (o.kind == FOP_CONV) snprintf(buf, sizeof buf, "CONV rows=%d mtiles=%d K=%dx%d(+%d) Cout=%d dst=%d%s", o.rows, o.mtiles, o.ntap, o.main_ph.nch * 16, o.nsc ? o.sc[0].nch * 16 : 0, o.Cout, o.dst_kind, o.gn_off >= 0 ? (o.gn_raw ? " +GN(copy)" : " +GN") : "");
+        const char* kn[] = {"GATHER", "STORE", "GN", "CONV", "ATTN", "LOADTAB", "XCHG"};
+        if (o.kind == FOP_CONV) snprintf(buf, sizeof buf, "CONV rows=%d mtiles=%d K=%dx%d(+%d) Cout=%d dst=%d%s", o.rows, o.mtiles, o.ntap, o.main_ph.nch * 16, o.nsc ? o.sc[0].nch * 16 : 0, o.Cout, o.dst_kind, o.gn_off >= 0 ? (o.gn_raw ? (o.coop ? " +GN(copy) coop" : " +GN(copy)") : (o.coop ? " +GN coop" : " +GN")) : (o.coop ? " coop" : ""));
         else snprintf(buf, sizeof buf, "%s rows=%d C=%d", kn[o.kind], o.rows, o.C);
         c->fdesc.push_back(buf);
     }
@@ -1763,16 +1894,27 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(unet_wg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<false, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<true, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
         UnetArgs ua = fq->fargs;
         ua.x_in = f.x; ua.x_mod = f.x_mod; ua.out = f.out; ua.NB = f.NB;
-        const unsigned nwg = (unsigned)ceil_div(f.NB, fq->S);
+        unsigned nwg = (unsigned)ceil_div(f.NB, fq->S);
+        if (fq->coop) {          // groups of four workgroups, whole blocks of 4 * stride ids; every launch gets fresh exchange tags
+            nwg = (unsigned)(ceil_div(ceil_div(f.NB, 4), ua.coop_stride) * 4 * ua.coop_stride);
+            ua.epoch_base = c->coop_epoch;
+            c->coop_epoch += (unsigned)fq->n_xchg;
+            if (c->coop_epoch > 0xfff00000u) c->coop_epoch = 0;        // tags only have to differ from the two previous uses of a slot
+        }
         if (f.dense_rows) ua.dense = f.dense_rows;
         double fl = 0;
         for (auto& op : c->ops) fl += op.flops_per_sample;
         ProfScope ps(c, s, "unet_wg_kernel", fl * f.NB);
+        c->last_prog = (int)(fq - c->progs.data());
         if ((ua.stamps || ua.dbg) && fq->S == 1) hipLaunchKernelGGL(unet_wg_kernel<true>, dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);   // diagnostic build
+        else if ((ua.stamps || ua.dbg) && fq->coop) hipLaunchKernelGGL((unet_wg_kernel<true, true, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
+        else if (fq->coop) hipLaunchKernelGGL((unet_wg_kernel<false, true, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
         else if (fq->S > 1) hipLaunchKernelGGL((unet_wg_kernel<false, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
         else hipLaunchKernelGGL(unet_wg_kernel<false>, dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
         HIP_OK(hipGetLastError());
@@ -1901,7 +2043,7 @@ extern "C" {
 const char* rdmi_last_error(void) { return g_err.c_str(); }
 int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** desc, int desc_cap) {
     if (!c || !c->d_stamps || !c->fused_ready()) return 0;
-    const rdmi_ctx::FusedProg& q0 = c->progs[0];
+    const rdmi_ctx::FusedProg& q0 = c->progs[(size_t)std::min<int>(std::max(c->last_prog, 0), (int)c->progs.size() - 1)];     // the program of the last launch
     const int n = (int)q0.fprog.size();
     std::vector<long long> st((size_t)n + 1);
     if (n > 1000) return 0;
@@ -1926,6 +2068,10 @@ const char* rdmi_path_info(rdmi_ctx* c) {
     } else if (c->fused_ready() && c->use_fused && !c->debug_taps) {
         s = "fused: workgroup-resident U-Net, " + std::to_string(c->progs[0].fprog.size()) + " ops, " + std::to_string(c->progs[0].fused_lds) + " B LDS";
         for (size_t i = 1; i < c->progs.size(); ++i)
+            if (c->progs[i].coop)
+                s += c->progs[i].ok ? "; co-operative groups of 4 workgroups up to batch " + std::to_string(c->progs[i].max_nb) + " (" + std::to_string(c->progs[i].fprog.size()) + " ops, " + std::to_string(c->progs[i].n_xchg) + " exchanges, id stride " + std::to_string(c->coop_stride) + (c->use_coop ? ")" : ", disabled)")
+                                    : "; co-operative program unavailable (" + c->progs[i].why + ")";
+            else
             s += c->progs[i].ok ? "; S=" + std::to_string(c->progs[i].S) + " samples/workgroup from batch " + std::to_string(c->s_min_wg * c->progs[i].S) + " (" + std::to_string(c->progs[i].fprog.size()) + " ops)"
                                 : "; S=" + std::to_string(c->progs[i].S) + " unavailable (" + c->progs[i].why + ")";
     } else {
@@ -1934,6 +2080,24 @@ const char* rdmi_path_info(rdmi_ctx* c) {
     return s.c_str();
 }
 
+int rdmi_philox_normal(float* z, size_t n, unsigned long long seed, unsigned long long elem_offset, unsigned draw, void* stream) {
+    if (n == 0) return 0;
+    if (!z) return fail("null argument");
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((n + 4 * RDMI_THREADS - 1) / (4 * RDMI_THREADS))), dim3(RDMI_THREADS), 0, (hipStream_t)stream, z, (long)n,
+                       (uint64_t)seed, (uint64_t)elem_offset, (const int*)nullptr, (int)draw);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// 0: no co-operative exchange of this context has ever given up its bounded wait; 1: one did (the affected output samples are NaN).
+// Synchronises the device (diagnostic: tests and bench.py call it after their timed regions).
+int rdmi_coop_status(rdmi_ctx* c, int* gave_up) {
+    if (!c || !gave_up) return fail("null argument");
+    *gave_up = 0;
+    for (auto& q : c->progs)
+        if (q.coop && q.d_coop_err) { int v = 0; HIP_OK(hipMemcpy(&v, q.d_coop_err, sizeof v, hipMemcpyDeviceToHost)); *gave_up |= v; }
+    return 0;
+}
 const char* rdmi_version(void) {
 #ifdef RDMI_EMU
     return "rdmi 0.1 (CPU execution-model emulator build: tests only)";
@@ -1974,7 +2138,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         train_registry().erase(c);
         delete T;
     }
-    for (auto& q : c->progs) for (void* p : {(void*)q.d_fprog, (void*)q.d_ftabs, (void*)q.d_spill}) if (p) hipFree(p);
+    for (auto& q : c->progs) for (void* p : {(void*)q.d_fprog, (void*)q.d_ftabs, (void*)q.d_spill, (void*)q.d_xbuf, (void*)q.d_coop_err}) if (p) hipFree(p);
     void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all, c->t_ws, c->t_xin, c->t_out, c->d_w16};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }

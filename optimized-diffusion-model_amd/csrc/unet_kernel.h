@@ -24,6 +24,10 @@
 #ifndef UW_PF_N1
 #define UW_PF_N1 4
 #endif
+#ifndef UW_PF_KS1
+#define UW_PF_KS1 9       // co-operative single-row-tile convs: a wave's K slice is 9-36 steps.  Measured: 4 and 9 equal (15.5 k cycles per 9x128 conv), 18 slower
+                          // (18.2 k: the whole 147 KB slice of a CU is requested before the first MFMA and arrives at the L2->CU rate, nothing overlaps)
+#endif
 #ifndef UW_PRIO
 #define UW_PRIO 0
 #endif
@@ -42,7 +46,7 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
-enum { FOP_GATHER = 0, FOP_STORE = 1, FOP_GN = 2, FOP_CONV = 3, FOP_ATTN = 4, FOP_LOADTAB = 5 };
+enum { FOP_GATHER = 0, FOP_STORE = 1, FOP_GN = 2, FOP_CONV = 3, FOP_ATTN = 4, FOP_LOADTAB = 5, FOP_XCHG = 6 };
 
 struct FPhase {            // one K-phase of a contraction: A rows come from an LDS tensor through a row table
     int lds_off;           // byte offset of the A tensor in LDS
@@ -68,6 +72,7 @@ struct FOp {
     int G, act; float eps;                        // GN (src_off >= 0: read from that LDS tensor, write dst: fused copy)
     int src_off, src_rs;
     int logT, Cg, magic_c4n, magic_Cg; float inv_cnt;   // GN: host-precomputed (no integer/float divisions on the device)
+    int logG;                                     // GN: log2(G); multi-sample ops spread the ns * G (sample, group) pairs over the workgroup
     const float* gamma; const float* beta;
     int ntap; int tab_off[9];                     // CONV main phases (taps) share lds/rs/nch, weights contiguous
     FPhase main_ph;                               //   (tab_off of main_ph unused; per-tap tables in tab_off[])
@@ -93,6 +98,15 @@ struct FOp {
     // streamed weight fragment feeds S samples).  hw_shift = log2(rows per sample) for multi-sample ops (hw is 4 or 16).
     int samp, hw_shift;
     int qkv1;                                     // CONV dst_kind 3: run as the single-pass q/k/v projection (fconv_qkv)
+    // ---- co-operative program (UnetArgs::coop: four workgroups = four CUs share the low-resolution section of their four samples)
+    int coop;                                     // CONV: this workgroup computes only ITS quarter of the output columns (member m: column tiles
+                                                  // [m * ntiles/4, (m+1) * ntiles/4)) for ALL four samples, K split over the wave groups (fop_conv_coop)
+    int a_mstride;                                // GATHER: byte offset added to a_off per member (a member's own rows of a multi-sample tensor)
+    // ---- XCHG: all-gather of an LDS tensor between the four members of a group (fop_xchg).  dst_off / dst_rs / rows: the tensor;
+    //      C: slice width.  a_hw = 0: every member owns columns [m*C, m*C+C) of all `rows` rows (src_off >= 0: a second tensor of the same
+    //      shape travels in the same exchange).  a_hw = 1: every member owns `rows` rows ([m*rows, (m+1)*rows)) of all C columns, its
+    //      own block is the single-sample tensor a_off / a_rs.  xidx: index of this exchange in the program (epoch tag and slot parity).
+    int xidx;
 };
 
 struct UnetArgs {
@@ -110,6 +124,14 @@ struct UnetArgs {
                                                   // bodies, bit 3 CONV, bit 4 ATTN, bit 5 GATHER/STORE, bits 6/7 GN statistics / apply,
                                                   // bit 8 conv epilogues, bit 9 conv main loops (scripts/gpu_ablate.py)
     long long* stamps;                            // diagnostic: per-op shader-clock stamps of workgroup 0 (null in production)
+    // co-operative program: groups of four workgroups (ids b, b + coop_stride, b + 2*coop_stride, b + 3*coop_stride inside each block of
+    // 4*coop_stride ids: with stride 8 the four sit on one XCD under round-robin placement -- speed only, never correctness)
+    int coop, coop_stride;
+    unsigned long long* xbuf;                     // exchange slots [group][parity][member][xslot] of 8-byte {value, tag} granules (zeroed once)
+    int xslot;                                    // granules per member slot
+    unsigned epoch_base;                          // tag of exchange x of this launch = epoch_base + x + 1 (host: advanced by the program's exchange count per launch)
+    int out_elems;                                // floats per sample of the network output
+    int* coop_err;                                // set to 1 by a workgroup whose bounded wait gave up (its output sample is then NaN)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -141,10 +163,11 @@ __device__ __forceinline__ float* lds_f(int off) { return reinterpret_cast<float
 __device__ __forceinline__ int samp_of(int samp, int hw_shift, int row) { return samp >= 0 ? samp : (row >> hw_shift); }
 
 template <bool MS>
-__device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int n0, int tid) {
+__device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int n0, int ncap, int member, int tid) {
     struct { int C, rows, dst_off, dst_rs, CA, CB, a_off, a_rs, a_hw, a_mod, a_map_off, b_off, b_rs, samp, hw_shift; const float* a_g; const float* b_g; } o;
     o.C = OPI(w, C); o.rows = OPI(w, rows); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.CA = OPI(w, CA); o.CB = OPI(w, CB);
     o.a_off = OPI(w, a_off); o.a_rs = OPI(w, a_rs); o.a_hw = OPI(w, a_hw); o.a_mod = OPI(w, a_mod); o.a_map_off = OPI(w, a_map_off);
+    if (MS && o.a_off >= 0) o.a_off += member * OPI(w, a_mstride);        // co-operative program: this member's rows of a multi-sample tensor
     o.b_off = OPI(w, b_off); o.b_rs = OPI(w, b_rs); o.a_g = OPP(w, const float, a_g); o.b_g = OPP(w, const float, b_g);
     o.samp = MS ? OPI(w, samp) : 0; o.hw_shift = MS ? OPI(w, hw_shift) : 0;
     const int Cd = o.C;                               // padded total channels (multiple of 4)
@@ -162,7 +185,7 @@ __device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int 
         const int c = c4 << 2;
         const int sl = samp_of(o.samp, o.hw_shift, row);             // sample slot and pixel of this destination row
         const int px = o.samp >= 0 ? row : row - (sl << o.hw_shift);
-        const int n = min(n0 + sl, u.NB - 1);
+        const int n = min(n0 + sl, ncap - 1);
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
         if (c < o.CA) {
             const int srow = map ? map[px] : px;
@@ -187,7 +210,7 @@ __device__ __forceinline__ void fop_gather(const OpW& w, const UnetArgs& u, int 
 }
 
 template <bool MS>
-__device__ __forceinline__ void fop_store(const OpW& w, const UnetArgs& u, int n0, int tid) {
+__device__ __forceinline__ void fop_store(const OpW& w, const UnetArgs& u, int n0, int ncap, int tid) {
     struct { int C, rows, dst_off, dst_rs, samp, hw_shift; float* g_out; } o;
     o.C = OPI(w, C); o.rows = OPI(w, rows); o.dst_off = OPI(w, dst_off); o.dst_rs = OPI(w, dst_rs); o.g_out = OPP(w, float, g_out);
     o.samp = MS ? OPI(w, samp) : 0; o.hw_shift = MS ? OPI(w, hw_shift) : 0;
@@ -200,20 +223,28 @@ __device__ __forceinline__ void fop_store(const OpW& w, const UnetArgs& u, int n
     for (int i = tid; i < total; i += UW_THREADS) {
         const int sl = samp_of(o.samp, o.hw_shift, row);
         const int px = o.samp >= 0 ? row : row - (sl << o.hw_shift);
-        const int n = min(n0 + sl, u.NB - 1);        // duplicate slots of a tail workgroup store the same values to the same place
+        const int n = min(n0 + sl, ncap - 1);        // duplicate slots of a tail workgroup store the same values to the same place
         stg4(o.g_out + ((size_t)n * hw + px) * o.C + (c4 << 2), *reinterpret_cast<const f32x4*>(src + (size_t)row * o.dst_rs + (c4 << 2)));
         row += dpv; c4 += dc4;
         if (c4 >= c4n) { c4 -= c4n; ++row; }
     }
 }
 
-// sum over aligned groups of 2^logT lanes (8, 16, 32 or 64): DPP row reductions (common.h), no LDS-crossbar shuffles
+// sum over the 4 lanes of a quad (columns 4q..4q+3 of a 16-column tile): two VALU-DPP steps
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float quad_sum(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); return v; }
+#else
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+#endif
+
+// sum over aligned groups of 2^logT lanes (4, 8, 16, 32 or 64): DPP row reductions (common.h), no LDS-crossbar shuffles
 __device__ __forceinline__ float group_sum_rt(float v, int logT, int lane) {
     switch (logT) {
         case 6: return group64_sum(v);
         case 5: return group32_sum(v, lane);
         case 4: return row16_sum(v);
-        default: return row8_sum(v);
+        case 3: return row8_sum(v);
+        default: return quad_sum(v);       // 4 lanes per group (multi-sample ops)
     }
 }
 
@@ -241,8 +272,11 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
     // this lane's share of the group: rows sub, sub+T, ... (<= 6 rows for 96 pixels at T = 16), Cg <= 8 channels
     constexpr int MAXR = 6;
     if (!(dbg & 64)) {
-    for (int sm = 0; sm < ns; ++sm) {
-    const float* base = S0 + (size_t)sm * o_rows * srs + g * Cg;
+    {
+    // multi-sample ops: the ns * G (sample, group) pairs are spread over the workgroup (vg = sm * G + gq, T = 512 / (ns * G) lanes
+    // each): all samples' statistics form in ONE pass instead of one pass per sample
+    const int sm = MS ? (g >> OPI(w, logG)) : 0, gq = MS ? (g & (o_G - 1)) : g;
+    const float* base = S0 + (size_t)sm * o_rows * srs + gq * Cg;
     f32x4 v0[MAXR], v1[MAXR];
     float sum = 0.f;
     // Branch-free over rows: every lane loads its (clamped) rows back to back -- all reads in flight before the first
@@ -282,7 +316,7 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
         sq += rw[k] * q;
     }
     sq = group_sum_rt(sq, logT, tid & 63);
-    if (sub == 0) { stat[(sm * o_G + g) * 2] = mean; stat[(sm * o_G + g) * 2 + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
+    if (sub == 0) { stat[g * 2] = mean; stat[g * 2 + 1] = 1.0f / sqrtf(sq * inv_cnt + o_eps); }
     }
     }
     // fixed channel quad per work-item: rows advance by rstep; work-items beyond rstep*c4n idle (C = 192)
@@ -292,16 +326,28 @@ __device__ __forceinline__ void fop_gn(const OpW& w, float* stat, int tid, f32x4
     const bool active = r0 < rstep;
     lds_barrier();
     if (active && !(dbg & 128)) {
-        for (int sm = 0; sm < ns; ++sm) {
-            float* X = X0 + (size_t)sm * o_rows * rs;
-            const float* S = S0 + (size_t)sm * o_rows * srs;
+        if (!MS || ns == 1) {
             f32x4 mu, rstd;
-            for (int j = 0; j < 4; ++j) { const int gg = sm * o_G + (((c + j) * mg_Cg) >> 16); mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
+            for (int j = 0; j < 4; ++j) { const int gg = ((c + j) * mg_Cg) >> 16; mu[j] = stat[2 * gg]; rstd[j] = stat[2 * gg + 1] * pgm[j]; }
             for (int row = r0; row < o_rows; row += rstep) {
-                float* p = X + (size_t)row * rs + c;
-                f32x4 val = *reinterpret_cast<const f32x4*>(S + (size_t)row * srs + c);
+                float* p = X0 + (size_t)row * rs + c;
+                f32x4 val = *reinterpret_cast<const f32x4*>(S0 + (size_t)row * srs + c);
                 for (int j = 0; j < 4; ++j) {
                     const float y = (val[j] - mu[j]) * rstd[j] + pbt[j];
+                    val[j] = o_act ? silu_f(y) : y;
+                }
+                *reinterpret_cast<f32x4*>(p) = val;
+            }
+        } else {                       // all samples' rows in one sweep; a row's statistics are its sample's
+            const int total = ns * o_rows;
+            int gq[4];
+            for (int j = 0; j < 4; ++j) gq[j] = ((c + j) * mg_Cg) >> 16;
+            for (int row = r0; row < total; row += rstep) {
+                const int sb = (row >> hw_shift) * o_G;
+                float* p = X0 + (size_t)row * rs + c;
+                f32x4 val = *reinterpret_cast<const f32x4*>(S0 + (size_t)row * srs + c);
+                for (int j = 0; j < 4; ++j) {
+                    const float y = (val[j] - stat[2 * (sb + gq[j])]) * (stat[2 * (sb + gq[j]) + 1] * pgm[j]) + pbt[j];
                     val[j] = o_act ? silu_f(y) : y;
                 }
                 *reinterpret_cast<f32x4*>(p) = val;
@@ -326,13 +372,6 @@ __device__ __forceinline__ int arow(const short* tab, int m, int lds_off, int rs
     return r < 0 ? zero_off : lds_off + r * rs * 4;
 }
 
-// sum over the 4 lanes of a quad (columns 4q..4q+3 of a 16-column tile): two VALU-DPP steps
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float quad_sum(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); return v; }
-#else
-__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
-#endif
-
 // One wave's share of a CONV op, main loop: NMT row tiles (starting at tile mt0, stride WM) x one column tile -> acc[0..NMT-1].
 //  * weights stream through a PF-deep register ring of straight-line global loads (the compiler waits with
 //    vmcnt(PF-1), never draining the ring); the step count is padded up to a multiple of PF with steps whose A
@@ -340,8 +379,11 @@ __device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 1); v +=
 //    must stay resident in the 64 KiB I-cache or every op transition refetches cold code);
 //  * A fragments are read from LDS one step ahead of the MFMAs that consume them.
 // The epilogue (fconv_epi) is shared by every instantiation: one copy of that code in the kernel.
-template <bool DIAG, int NMT, int PF, bool M4 = false, bool LM4 = false>
-__device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int mt0, int WM, int nt, int lane, long long* fine, f32x4 (&acc)[4]) {
+// KS (co-operative program): the K steps are dealt round-robin to four wave groups -- this wave takes steps kg, kg + 4, ... of the
+// (tap, 16-channel chunk) sequence (the chunk count is a multiple of 4, so it is chunk kg, kg + 4, ... of every tap); acc[] are
+// PARTIAL sums that fop_conv_coop adds up.
+template <bool DIAG, int NMT, int PF, bool M4 = false, bool LM4 = false, bool KS = false>
+__device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int mt0, int WM, int nt, int lane, long long* fine, f32x4 (&acc)[4], int kg = 0) {
     const int lrow = lane & 15, kq = lane >> 4;
     if (DIAG && fine) fine[0] = clock64();
     const int o_Cout_pad = OPI(w, Cout_pad), o_ntap = OPI(w, ntap);
@@ -358,14 +400,14 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
     for (int i = 0; i < NMT; ++i)      // M4: images of <= 4 pixels; LM4: the LAST row tile has <= 4 real rows (81 = 5 x 16 + 1)
         mrow[i] = (mt0 + i * WM) * 16 + ((M4 || (LM4 && i == NMT - 1)) ? (lane & 3) : lrow);
     {
-        const int nsteps = o_ntap * nch;
+        const int nsteps = KS ? (o_ntap * nch) >> 2 : o_ntap * nch;
         const int npad = (DIAG && (u.dbg & 512)) ? 0 : ((nsteps + PF - 1) / PF) * PF;     // ablation: no main loop
-        const size_t bstride = (size_t)o_Cout_pad * 16;
-        const float* Wl = m_w + (size_t)col * 16 + kq * 4;
+        const size_t bstride = (size_t)o_Cout_pad * (KS ? 64 : 16);
+        const float* Wl = m_w + (size_t)col * 16 + kq * 4 + (KS ? (size_t)kg * o_Cout_pad * 16 : 0);
         f32x4 ring[PF];
 #pragma unroll
         for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nsteps - 1) * bstride);
-        int ph = 0, ch = 0;
+        int ph = 0, ch = KS ? kg : 0;
         // row offsets of the current tap and, one tap AHEAD, of the next one: the table lookup (LDS read + address math)
         // of a tap transition is issued a whole tap early, so the transition itself is a register move
         int abase[NMT], anext[NMT];
@@ -377,7 +419,7 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
         }
         f32x4 afn[NMT];
 #pragma unroll
-        for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i]);
+        for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + (KS ? kg * 64 : 0));
         if (DIAG && fine) fine[1] = clock64();
         for (int q = 0; q < npad; q += PF) {
 #pragma unroll
@@ -386,8 +428,11 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
 #pragma unroll
                 for (int i = 0; i < NMT; ++i) af[i] = afn[i];
                 // advance to the next step and issue its A reads before this step's MFMAs
-                if (++ch == nch) {
-                    ch = 0; ++ph;
+                bool wrap;
+                if (KS) { ch += 4; wrap = ch >= nch; if (wrap) ch -= nch; }
+                else { wrap = ++ch == nch; if (wrap) ch = 0; }
+                if (wrap) {
+                    ++ph;
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) abase[i] = anext[i];
                     if (ph + 1 < o_ntap) {
@@ -786,6 +831,161 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Co-operative program (UnetArgs::coop): a group of four workgroups -- four CUs -- owns four samples.  Every member runs the
+// full-resolution sections for ITS sample alone (the S = 1 ops) and the low-resolution section for ALL four samples, but only
+// its quarter of every conv's output columns: a CU then streams a quarter of the 17.7 MB of low-resolution weights per forward
+// (that section is weight-stream bound with one sample per CU) and every weight fragment it does stream feeds four samples
+// (16 rows at 2x2: a full 16x16x4 MFMA tile).  After each 3x3 conv the members all-gather the tensor the next conv contracts
+// over (fop_xchg).  Nothing else is shared: skip tensors are spilled per workgroup, GroupNorm / gather ops of concat tensors
+// run redundantly on the complete tensor.
+//
+// CONV of the co-operative low-resolution section: member m computes column tiles [2m, 2m+2) (Cout_pad = 128) for all rows.
+// The 8 waves are (column tile ct = wave & 1) x (K group kg = wave >> 1): wave (ct, kg) accumulates PARTIAL sums over K steps
+// kg, kg+4, ... for every row tile (1 at 2x2, 4 at 4x4).  Row tile i is finished by the wave with kg == i (kg == 0 when there is
+// one row tile): the other three park their partials of that tile in the destination tensor's FOREIGN columns -- dead space
+// until the exchange fills it -- and after one barrier the finisher adds the four partials in the fixed order kg = 0..3
+// (run-to-run identical) and runs the common epilogue (bias, Dense_0 row, residual, scale, fused GroupNorm) on its tile.
+template <bool DIAG>
+__device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, int n_grp, int m, int wave, int lane, long long* fine) {
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int ct = wave & 1, kg = wave >> 1;
+    const int mtiles = OPI(w, mtiles);                         // 1 or 4 (host-checked)
+    const int nt = 2 * m + ct, col = nt * 16 + lrow;
+    const int o_Cout = OPI(w, Cout), o_dense = OPI(w, dense_off), hw_shift = OPI(w, hw_shift);
+    const float* o_bias = OPP(w, const float, bias); const float* o_bias2 = OPP(w, const float, bias2);
+    const bool fused_gn = OPI(w, gn_off) >= 0;
+    const int mt_e = mtiles == 4 ? kg : 0;                     // the row tile this wave finishes ...
+    const bool finisher = mtiles == 4 || kg == 0;              // ... if it finishes one
+    float add = 0.f, gmul = 1.f, gadd = 0.f;
+    float dadd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (finisher && col < o_Cout) {                            // epilogue operands: their latency hides under the main loop
+        add = ldg1(o_bias + col);
+        if (o_bias2) add += ldg1(o_bias2 + col);
+        if (fused_gn) { gmul = ldg1(OPP(w, const float, gamma) + col); gadd = ldg1(OPP(w, const float, beta) + col); }
+        if (o_dense >= 0) {
+            const int sl = (mt_e * 16 + kq * 4) >> hw_shift;
+            dadd[0] = ldg1(u.dense + (size_t)o_dense + (size_t)min(n_grp + sl, u.NB - 1) * u.dense_stride + col);
+        }
+    }
+    f32x4 acc[4];
+    if (mtiles == 4) fconv_main<DIAG, 4, 4, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
+    else fconv_main<DIAG, 1, UW_PF_KS1, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
+    // park the partials this wave does not finish: tile i of K group kg goes to foreign column block (m + ((kg - fin(i)) & 3)) & 3
+    float* const dstp = lds_f(OPI(w, dst_off));
+    const int drs = OPI(w, dst_rs);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < mtiles) {
+            const int fin = mtiles == 4 ? i : 0;
+            if (kg != fin) {
+                float* p = dstp + (size_t)(i * 16 + kq * 4) * drs + (((m + ((kg - fin) & 3)) & 3) * 32 + ct * 16 + lrow);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r * drs] = acc[i][r];
+            }
+        }
+    lds_barrier();
+    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fin_acc[4];
+    bool have_gn = false;
+    if (finisher) {
+        f32x4 own = mtiles == 4 ? (kg == 0 ? acc[0] : kg == 1 ? acc[1] : kg == 2 ? acc[2] : acc[3]) : acc[0];
+        f32x4 part[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {           // K group k's partial of my tile: mine from registers, the others from their parking block
+            const float* p = dstp + (size_t)(mt_e * 16 + kq * 4) * drs + (((m + ((k - kg) & 3)) & 3) * 32 + ct * 16 + lrow);
+            for (int r = 0; r < 4; ++r) part[k][r] = k == kg ? own[r] : p[r * drs];
+        }
+        fin_acc[0] = (part[0] + part[1]) + (part[2] + part[3]);
+        if (!(DIAG && (u.dbg & 256))) have_gn = fconv_epi<true>(w, u, n_grp, mt_e, 1, nt, 1, lane, add, dadd, fin_acc, ps1, ps2);
+    }
+    if (fused_gn) {
+        lds_barrier();
+        if (have_gn) fconv_gn_apply<true>(w, mt_e, 1, nt, 1, lane, gmul, gadd, fin_acc, ps1, ps2);
+    }
+}
+
+// XCHG: all-gather of one (or two) LDS tensors between the four members of a group.  Every member publishes the block it owns
+// as 16-byte pairs of {value, tag} granules (device-scope write-through stores) into ITS slot of the exchange buffer and reads
+// the other three members' slots with device-scope loads until every tag equals this exchange's epoch -- the data is the
+// flag: no fence, no separate flag word, correct under any workgroup placement.  Slots alternate with the parity of the
+// exchange index: a member can be at most one exchange ahead of another (it cannot pass exchange x+1 before every member has
+// published x+1, i.e. has finished reading x), so two slots suffice.  All of a thread's loads are in flight together
+// (12 x 16 B at most); the wait is bounded: on give-up the workgroup flags the launch (UnetArgs::coop_err, *failw).
+__device__ __forceinline__ void fop_xchg(const OpW& w, const UnetArgs& u, int g, int m, int tid, int* failw) {
+    const int mode = OPI(w, a_hw), rows = OPI(w, rows), Cs = OPI(w, C), xi = OPI(w, xidx);
+    const int d_off = OPI(w, dst_off), d_rs = OPI(w, dst_rs), s_off = OPI(w, src_off), s_rs = OPI(w, src_rs);
+    const int a_off = OPI(w, a_off), a_rs = OPI(w, a_rs);
+    const unsigned epoch = u.epoch_base + (unsigned)xi + 1u;
+    const int csh = 31 - __builtin_clz((unsigned)Cs);      // slice width is a power of two (host-checked)
+    const int half = (rows << csh) >> 1;                   // granule pairs per tensor block
+    const int np = s_off >= 0 ? 2 * half : half;
+    const unsigned slotb = (unsigned)u.xslot * 8u;         // bytes per member slot
+    const unsigned gbase = (unsigned)((g * 2 + (xi & 1)) * 4) * slotb;
+    const XBuf xb = xbuf_make(u.xbuf, 0x7fffffffu);
+    // float index in LDS of pair p's first element, for member j's block
+    auto at = [&](int p, int j) -> int {
+        const int sel = p >= half ? 1 : 0, i = (p - sel * half) << 1, row = i >> csh, c = i & (Cs - 1);
+        if (mode == 0) return ((sel ? s_off : d_off) >> 2) + row * (sel ? s_rs : d_rs) + j * Cs + c;
+        return (d_off >> 2) + (j * rows + row) * d_rs + c;
+    };
+    typedef float f32x2 __attribute__((vector_size(8)));
+    constexpr int KMAX = 4;
+    // NOTE (ROCm 7.2 clang): __builtin_bit_cast applied DIRECTLY to a vector element (bit_cast<T>(v[i])) reads element 0 whatever i is
+    // -- copy the element into a scalar first.
+    // ---- publish my block (mode 1: it comes from the single-sample tensor a_off and is also copied into my rows of the destination)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = tid + k * UW_THREADS;
+        if (p < np) {
+            f32x2 v;
+            if (mode == 0) v = *reinterpret_cast<const f32x2*>(lds_f(0) + at(p, m));
+            else {
+                const int i = p << 1, row = i >> csh, c = i & (Cs - 1);
+                v = *reinterpret_cast<const f32x2*>(lds_f(a_off) + row * a_rs + c);
+                *reinterpret_cast<f32x2*>(lds_f(0) + at(p, m)) = v;
+            }
+            const float v0 = v[0], v1 = v[1];
+            xbuf_store16(xb, gbase + (unsigned)m * slotb + (unsigned)p * 16u, __builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1), epoch);
+        }
+    }
+    // ---- gather the other three blocks: every pass issues ALL of this thread's loads back to back (clamped to a valid pair, so
+    //      there is no branch between them), then looks at the tags
+    const int nk = (np + UW_THREADS - 1) / UW_THREADS;          // passes over the pairs (wave-uniform)
+    u32x4 y[3 * KMAX];
+    unsigned long long spins = 0;
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < nk) {
+                const unsigned po = (unsigned)min(tid + k * UW_THREADS, np - 1) * 16u;
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) y[k * 3 + jj] = xbuf_load16(xb, gbase + (unsigned)((m + 1 + jj) & 3) * slotb + po);
+            }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < nk) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) { const unsigned t1 = y[k * 3 + jj][1], t3 = y[k * 3 + jj][3]; ok &= t1 == epoch && t3 == epoch; }
+            }
+        if (ok) break;
+        if (++spins > RDMI_SPIN_LIMIT) { *failw = 1; *u.coop_err = 1; break; }
+        spin_relax();
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = tid + k * UW_THREADS;
+        if (k < nk && p < np) {
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const unsigned a = y[k * 3 + jj][0], b = y[k * 3 + jj][2];
+                *reinterpret_cast<f32x2*>(lds_f(0) + at(p, (m + 1 + jj) & 3)) = f32x2{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+            }
+        }
+    }
+}
+
 // Attention core on LDS tensors: P = softmax(Q K^T * scale) (rows = queries), O = P V.
 // Q, K: [L][qk_rs]; Vt: [C][ps] (keys along the row, all Lpad columns finite); P: [L][ps]; O -> dst [L][dst_rs].
 // C = 64 channels (one 16-wide channel tile per wave pair).
@@ -881,12 +1081,23 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
 // DIAG = true is the diagnostic build of the same kernel (per-op cycle stamps, per-op-kind ablation); the production
 // instantiation compiles all of that away -- the interpreter has to stay inside the 64 KiB instruction cache.
 // MS = true: the program may hold multi-sample ops (S > 1 samples per workgroup); MS = false compiles every trace of that away
-// (the S = 1 program that serves B <= 128 with guidance keeps its leaner code).
-template <bool DIAG, bool MS = false>
+// (the S = 1 program keeps its leaner code).  COOP = true (with MS): the co-operative program -- see fop_conv_coop.
+template <bool DIAG, bool MS = false, bool COOP = false>
 __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = MS ? blockIdx.x * u.S : blockIdx.x;                       // first sample of this workgroup (ops add their slot)
+    // sample bookkeeping.  n: first sample of this workgroup's single-sample ops (ops add their slot); n_multi: first sample of
+    // its multi-sample ops; n_spill / spill_cap: sample index (and bound) under which multi-sample ops address the spill buffer.
+    int n = MS ? blockIdx.x * u.S : blockIdx.x, n_multi = n, n_spill = n, spill_cap = u.NB;
+    int cg = 0, cm = 0;                                                        // co-operative group and member index
+    if (COOP) {
+        const int st = u.coop_stride, bid = blockIdx.x, blk = bid / (4 * st), r = bid - blk * 4 * st;
+        cm = r / st; cg = blk * st + (r - cm * st);
+        if (cg * 4 >= u.NB) return;                                            // a group without a real sample: all four members leave
+        n = min(cg * 4 + cm, u.NB - 1);                                        // a member beyond the batch recomputes the last sample
+        n_multi = cg * 4;
+        n_spill = bid * 4; spill_cap = 0x7fffffff;                             // every member spills all four samples' skip tensors privately
+    }
     // tables + zero row
     {
         const int nw = u.tab_bytes >> 2;
@@ -902,6 +1113,8 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     if (wave < 4) __builtin_amdgcn_s_setprio(1);
 #endif
     float* stat = lds_f(u.zero_off + u.zero_bytes);      // [2 * 32] GroupNorm scratch right after the zero row
+    int* const failw = reinterpret_cast<int*>(stat) + 270;      // co-operative program: "an exchange gave up" (last word of the scratch block)
+    if (COOP && tid == 0) *failw = 0;
     if (DIAG && u.stamps && n == 0 && tid == 0) u.stamps[0] = clock64();
     // descriptors are kept TWO ops ahead (cur, nxt resident; the load for pc+2 is in flight) so that small operands
     // of the next op can be prefetched while the current one runs
@@ -918,11 +1131,15 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         if (pc + 1 < u.nops) gn_prefetch(nxt, tid, ngm, nbt);
         if (DIAG && fine) fine[3] = clock64();
         const int skip = (DIAG && u.dbg) ? ((kind == FOP_GN ? 4 : kind == FOP_CONV ? 8 : kind == FOP_ATTN ? 16 : 32) & u.dbg) : 0;
+        const bool multi = MS && OPI(cur, samp) < 0;
         switch (skip ? -1 : kind) {
-            case FOP_GATHER: fop_gather<MS>(cur, u, n, tid); break;
-            case FOP_STORE: fop_store<MS>(cur, u, n, tid); break;
+            case FOP_GATHER: fop_gather<MS>(cur, u, multi ? n_spill : n, multi ? spill_cap : u.NB, COOP ? cm : 0, tid); break;
+            case FOP_STORE: fop_store<MS>(cur, u, multi ? n_spill : n, multi ? spill_cap : u.NB, tid); break;
             case FOP_GN: fop_gn<MS>(cur, stat, tid, pgm, pbt, DIAG ? u.dbg : 0); break;
-            case FOP_CONV: fop_conv<DIAG, MS>(cur, u, n, wave, lane, fine); break;
+            case FOP_CONV:
+                if (COOP && OPI(cur, coop)) fop_conv_coop<DIAG>(cur, u, n_multi, cm, wave, lane, fine);
+                else fop_conv<DIAG, MS>(cur, u, multi ? n_multi : n, wave, lane, fine);
+                break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             case FOP_LOADTAB: {      // row tables of the multi-sample section: global -> their LDS block
                 const int* src = OPP(cur, const int, a_g);
@@ -931,6 +1148,7 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
                 for (int i = tid; i < nw; i += UW_THREADS) dst[i] = src[i];
                 break;
             }
+            case FOP_XCHG: if (COOP) fop_xchg(cur, u, cg, cm, tid, failw); break;
             default: break;
         }
         // ops that stored to global memory (skip spills, the network output) end with the full barrier: their stores must have
@@ -939,5 +1157,9 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
         else lds_barrier();
         if (DIAG && u.stamps && n == 0 && tid == 0) u.stamps[pc + 1] = clock64();
         cur = nxt; nxt = nn; pgm = ngm; pbt = nbt;
+    }
+    if (COOP && *failw) {                                   // an exchange of this workgroup gave up: its result is not the network's -- make that loud
+        const int E = (int)u.out_elems;
+        for (int i = tid; i < E; i += UW_THREADS) u.out[(size_t)n * E + i] = __builtin_nanf("");
     }
 }

@@ -83,6 +83,8 @@ _PROTOS = {
                           C.POINTER(C.c_double)], C.c_int),
     'rdmi_path_info': ([C.c_void_p], C.c_char_p),
     'rdmi_debug_op_cycles': ([C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_char_p), C.c_int], C.c_int),
+    'rdmi_coop_status': ([C.c_void_p, C.POINTER(C.c_int)], C.c_int),
+    'rdmi_philox_normal': ([_F, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint, C.c_void_p], C.c_int),
     'rdmi_last_error': ([], C.c_char_p),
     'rdmi_version': ([], C.c_char_p),
 }
@@ -134,6 +136,16 @@ def ptr(t):
 
 def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
+
+
+def philox_normal(n, seed, elem_offset, draw, device):
+    """The sampler's own N(0,1) stream (rdmi_philox_normal): `n` values of noise tensor `draw` from global element `elem_offset` on."""
+    z = torch.empty(int(n), dtype=torch.float32, device=device)
+    require_device(z)
+    ctxm = torch.cuda.device(z.device) if z.is_cuda else _Null()
+    with ctxm:
+        check(lib().rdmi_philox_normal(ptr(z), z.numel(), int(seed), int(elem_offset), int(draw), stream_of(z)))
+    return z
 
 
 def require_device(t):
@@ -245,6 +257,13 @@ class Context:
 
     def path_info(self):
         return lib().rdmi_path_info(self._h).decode()
+
+    def coop_gave_up(self):
+        """True if a co-operative launch of this context ever gave up an inter-workgroup wait (synchronises the device)."""
+        v = C.c_int()
+        with self._guard():
+            check(lib().rdmi_coop_status(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_profiling(self, on):
         check(lib().rdmi_set_profiling(self._h, int(bool(on))))

@@ -49,6 +49,7 @@ const dim3& cur_tid() { return cur->tid; }
 int lane_id() { return cur->linear & 63; }
 
 static void yield_to_sched() { swapcontext(&cur->ctx, &blk->sched); }
+void relax() { std::this_thread::yield(); yield_to_sched(); }      // state stays READY: the scheduler comes back round-robin
 
 static void release_block() {
     for (auto& l : blk->lanes)
@@ -148,7 +149,7 @@ static void run_block(void (*tramp)(void*), void* args, dim3 bid, dim3 grid, dim
 static int n_workers() {
     const char* e = std::getenv("RDMI_EMU_THREADS");
     int n = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
-    return n < 1 ? 1 : (n > 16 ? 16 : n);
+    return n < 4 ? 4 : (n > 16 ? 16 : n);       // >= 4: the four workgroups of a co-operative group (consecutive ids here) must run concurrently
 }
 
 void launch(void (*tramp)(void*), void* args, dim3 grid, dim3 block, size_t lds) {

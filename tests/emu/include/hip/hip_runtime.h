@@ -38,6 +38,8 @@ void sync_block();
 // all 64 lanes of the calling wave deposit `n` bytes; returns pointer to the wave's [64][n] table
 const unsigned char* wave_exchange(const void* mine, size_t n);
 int lane_id();
+// a work-item that polls memory written by ANOTHER workgroup (an OS thread of its own): let the other fibers and threads run
+void relax();
 void launch(void (*tramp)(void*), void* packed_args, dim3 grid, dim3 block, size_t lds);
 }  // namespace emu
 
