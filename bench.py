@@ -139,6 +139,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert x.shape[0] == B * world and bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
+    ctx0 = model._ctx[(str(dev), args.height, args.width)]
+    assert not ctx0.coop_gave_up(), 'a co-operative launch gave up an inter-workgroup wait (its samples are NaN): see DESIGN 4.2d'
+    # N > 1: how many ranks really took part (a sum of ones over the RCCL group) and what the one collective of the path costs alone
+    ranks_seen, gather_us = 1, None
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        shard = x[rank * B:(rank + 1) * B].contiguous()
+        full = torch.empty_like(x)
+        for _ in range(3):
+            dist.all_gather_into_tensor(full, shard)
+        sync(); tg = time.perf_counter()
+        for _ in range(20):
+            dist.all_gather_into_tensor(full, shard)
+        torch.cuda.synchronize()
+        gather_us = (time.perf_counter() - tg) / 20 * 1e6
 
     n_corr = 1 if args.corrector == 'langevin' else 0
     evals = (args.num_scales - 1) * (1 + n_corr)               # score evaluations per trajectory
@@ -155,6 +172,7 @@ def main():
                    'global_batch': B * world, 'num_scales': args.num_scales, 'score_evals_per_traj': evals,
                    'parallelism': f'batch-sharded x{world}, one all-gather per sampling call' if world > 1 else 'single GPU'},
         'tflops_algorithmic': value * fwd_per_traj * GFLOP_PER_FORWARD / 1e3 / world,
+        'plan': ctx0.path_info(), 'ranks_seen': ranks_seen, 'all_gather_us': gather_us,
     }
     if rank == 0 and not args.no_roofline:
         out['roofline'] = roofline(ge, model, cfg, sde, shape, labels, dev, args, value / world, fwd_per_traj)
@@ -233,6 +251,21 @@ def variants(ge, dev, args, labels):
                      'frac': (dom['flops'] / (dom['ms'] * 1e-3) / 1e12) / PEAK_FP32_MFMA_TFLOPS,
                      'whole_path_frac_of_fp32_peak': (B / dt) * 2 * (args.num_scales - 1) * (2 if corr == 'langevin' else 1) * gf / 1e3 / PEAK_FP32_MFMA_TFLOPS}
         del model
+    # A/B of the co-operative program (default at this batch): the same workload on the one-sample-per-workgroup program
+    os.environ['RDMI_COOP'] = '0'
+    try:
+        model, cfg, _ = ge.make_model(dev, num_scales=args.num_scales)
+        sde = sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=cfg.sde.num_scales)
+        fn = sampling.get_sampling_fn(cfg, sde, (B, 1, 9, 9), 1e-5, dev)
+        warm = sampling.get_sampling_fn(cfg, sde_lib.RVESDE(cfg.sde.sigma_min, cfg.sde.sigma_max, N=6), (B, 1, 9, 9), 1e-5, dev)
+        warm(model, weight=0.0, class_labels=labels)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        x, nfe = fn(model, weight=0.0, class_labels=labels)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out['coop_off'] = {'value': B / dt, 'unit': 'trajectories/s', 'ms_per_call': 1e3 * dt, 'plan': model._ctx[(str(dev), 9, 9)].path_info()}
+        del model
+    finally:
+        os.environ.pop('RDMI_COOP', None)
     # the reference's own operating point is B = 4096-8192 per GPU: from 512 model samples on, the
     # low-resolution half of the U-Net runs for 2 / 4 samples per workgroup (csrc/rdmi.hip: build_fused_program)
     for name, Bv, Nv in (('batch_1024', 1024, 1000), ('batch_4096', 4096, 251)):
@@ -369,8 +402,20 @@ def cpu_baseline(args, B):
         results[str(nthr)] = round(v, 4)
         if best is None or v > best[0]:
             best = (v, nthr, n, t_used)
+    # ... and ONE full run of the whole schedule at the best thread count ("run the full 1000 steps once if it fits")
+    full_s, full_v = None, None
+    if not lang and os.environ.get('RDMI_BENCH_NO_FULL_CPU') is None:
+        torch.set_num_threads(best[1])
+        x = x0.clone()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(args.num_scales - 1):
+                x = OT.pc_update(p, x, torch.full((B,), float(ts[i])), lab, w, torch.randn(x.shape, generator=g), args.num_scales)
+        full_s = time.perf_counter() - t0
+        full_v = B / full_s
+        assert bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
     return {'value': best[0], 'unit': 'trajectories/s', 'cores': best[1], 'kind': 'port', 'host_cpus': ncpu,
-            'threads_sweep': results,
+            'threads_sweep': results, 'full_run_s': full_s, 'full_run_value': full_v,
             'sample': f'{best[2]} PC updates of the same B={B} CFG batch ({best[3]:.1f} s) per thread count, scaled to '
                       f'{args.num_scales - 1} updates; best of the sweep'}
 

@@ -131,6 +131,9 @@ int rdmi_enable_training(rdmi_ctx* ctx);
 int rdmi_train_forward(rdmi_ctx* ctx, const float* x, const float* sigma, const float* labels, float* out, int B,
                        float dropout_p, uint64_t seed, void* stream);
 int rdmi_backward(rdmi_ctx* ctx, const float* grad_out, float* grads_flat, size_t grads_numel, const float* x, void* stream);
+/* Diagnostic: the train-mode forward and the backward are recorded as launch graphs on their second call and replayed from then on
+ * (RDMI_TRAIN_GRAPH=0: plain launches): how many recordings and replays this context has made. */
+int rdmi_train_graph_stats(rdmi_ctx* ctx, long* records, long* replays);
 
 /* One reflected Euler-Maruyama update given the score (RD/sampling.py:198-207 with
  * RSDE.sde, RD/sde_lib.py:93-101): x_mean = x + g(t)^2*score/N, x' = x_mean + g(t)*sqrt(1/N)*z,
@@ -210,6 +213,9 @@ typedef struct {
 } rdmi_opt_hyper;
 int rdmi_opt_create(const rdmi_opt_slot* slots_host, int n_slots, rdmi_opt** out);
 /* total_norm_out: NULL or a device float receiving the pre-clip global gradient norm (clip_grad_norm_'s return). */
+/* The same tensors at new addresses (e.g. this step's gradients landed in a fresh buffer): one asynchronous upload of the table,
+ * no allocation, no synchronisation.  Slot count and element counts must be those of rdmi_opt_create. */
+int rdmi_opt_update_slots(rdmi_opt* opt, const rdmi_opt_slot* slots_host, int n_slots, void* stream);
 int rdmi_opt_step(rdmi_opt* opt, const rdmi_opt_hyper* hyper, float* total_norm_out, void* stream);
 int rdmi_opt_destroy(rdmi_opt* opt);
 

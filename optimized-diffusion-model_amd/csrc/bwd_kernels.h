@@ -81,6 +81,7 @@ struct GnBwdArgs {
     const float* gamma; const float* beta; float* dgamma; float* dbeta;
     int G, has_gn; float eps;
     float drop_p; uint64_t seed; uint32_t op_id;
+    const unsigned long long* seed_dev;   // non-null: dropout seed in device memory (see ConvArgs::seed_dev)
     int a_bf16, b_bf16, s_bf16;   // element type of srcA, of srcB, and of the scratch tensors GA / ACT (0 fp32, 1 bf16)
     float* gA; float* gB; const int* inv_start; const int* inv_list;   // fp32 gradient accumulators (null: that source takes no gradient)
 };
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
                     const float xh = (V[(size_t)v * rs + c] - mean) * rstd;
                     const float y = xh * gm + bt;
                     const float sg = 1.0f / (1.0f + __expf(-y));
-                    const float ds = dropout_scale(a.seed, a.op_id, ((uint64_t)n * a.HWv + v) * a.Cv + c, a.drop_p);
+                    const float ds = dropout_scale(a.seed_dev ? (uint64_t)*a.seed_dev : a.seed, a.op_id, ((uint64_t)n * a.HWv + v) * a.Cv + c, a.drop_p);
                     stact1(a.ACT, base + (size_t)v * a.Cv + c, y * sg * ds, a.s_bf16);
                     const float gy = Gt[(size_t)v * rs + c] * ds * (sg * (1.0f + y * (1.0f - sg)));
                     dg += gy * xh; dbt += gy;

@@ -58,6 +58,7 @@ struct ConvArgs {
     float out_scale, eps;
     int S, BN, Mpad;
     float drop_p; uint64_t drop_seed; uint32_t op_id;   // train mode: dropout after GN+SiLU (Dropout_0, RD/models/layerspp.py:204)
+    const unsigned long long* seed_dev;   // non-null: the step's dropout seed is read from device memory (a recorded launch graph is replayed with a new seed)
     int bf16;                     // 1: wpk / wsc are the bf16 copies [tap][C/32][Cout_pad][32] and the MFMAs take bf16 operands (fp32 accumulate);
                                   //    needs Cv % 32 == 0 and Csc % 32 == 0 (training with compute_dtype = bf16, BASELINE config #4)
     int a_bf16, b_bf16, o_bf16;   // element type of srcA / scA, of srcB / scB / resid, and of out: 0 fp32, 1 bf16 (train_dtype = bf16 keeps the
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
                             if (left == 0) { ++gg; left = Cg; }
                             const float mu = stat[2 * (ss * G + gg)], rstd = stat[2 * (ss * G + gg) + 1];
                             val[j] = silu_f((val[j] - mu) * rstd * gm[j] + bt[j]);
-                            if (a.drop_p > 0.f) val[j] *= dropout_scale(a.drop_seed, a.op_id, ((uint64_t)(n0 + ss) * a.HWv + v) * a.Cv + c + j, a.drop_p);
+                            if (a.drop_p > 0.f) val[j] *= dropout_scale(a.seed_dev ? (uint64_t)*a.seed_dev : a.drop_seed, a.op_id, ((uint64_t)(n0 + ss) * a.HWv + v) * a.Cv + c + j, a.drop_p);
                             --left;
                         }
                     }
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void conv_mfma_kernel(ConvArgs a) {
                 if (left == 0) { ++gg; left = Cg; }
                 const float mu = stat[2 * (ss * G + gg)], rstd = stat[2 * (ss * G + gg) + 1];
                 val[j] = silu_f((val[j] - mu) * rstd * gm[j] + bt[j]);
-                if (a.drop_p > 0.f) val[j] *= dropout_scale(a.drop_seed, a.op_id, ((uint64_t)(n0 + ss) * a.HWv + v) * a.Cv + c + j, a.drop_p);
+                if (a.drop_p > 0.f) val[j] *= dropout_scale(a.seed_dev ? (uint64_t)*a.seed_dev : a.drop_seed, a.op_id, ((uint64_t)(n0 + ss) * a.HWv + v) * a.Cv + c + j, a.drop_p);
                 --left;
             }
             *reinterpret_cast<f32x4*>(p) = val;

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(RDMI_THREADS) void opt_norm_kernel(const float* __r
     if (tid == 0) {
         const float total = sqrtf(red[0]);
         out[0] = total;
-        out[1] = max_norm >= 0.f ? fminf(max_norm / (total + 1e-6f), 1.0f) : 1.0f;
+        // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total + 1e-6), clamped to 1.  A non-finite total norm must poison the
+        // whole step like torch's clamp does (fminf(NaN, 1) would return 1 and only the NaN elements would be hit)
+        const float coef = max_norm / (total + 1e-6f);
+        out[1] = max_norm >= 0.f ? (coef != coef ? coef : fminf(coef, 1.0f)) : 1.0f;
     }
 }
 

@@ -2133,6 +2133,11 @@ int rdmi_destroy(rdmi_ctx* c) {
             if (T->ev_ready[p]) (void)hipEventDestroy(T->ev_ready[p]);
             if (T->ev_done[p]) (void)hipEventDestroy(T->ev_done[p]);
         }
+        if (T->fwd_exec) (void)hipGraphExecDestroy(T->fwd_exec);
+        if (T->bwd_exec) (void)hipGraphExecDestroy(T->bwd_exec);
+        if (T->cap) (void)hipStreamDestroy(T->cap);
+        if (T->h_seed) (void)hipHostFree(T->h_seed);
+        for (void* p : {(void*)T->x_in, (void*)T->out_buf, (void*)T->gout_buf, (void*)T->grads_int, (void*)T->d_seed}) if (p) (void)hipFree(p);
         for (void* p : {(void*)T->d_jobs, (void*)T->d_wb, (void*)T->d_int, (void*)T->gws, (void*)T->GA, (void*)T->GS, (void*)T->zero_bias, (void*)T->gdense, (void*)T->gta, (void*)T->gh1, (void*)T->four, (void*)T->sig_copy, (void*)T->lab_copy,
                         (void*)T->d_gemm_jobs, (void*)T->d_col_jobs}) if (p) (void)hipFree(p);
         train_registry().erase(c);
@@ -2549,6 +2554,7 @@ int rdmi_ode_sample(rdmi_ctx* c, float* x, const float* labels, const float* wei
 
 // ---- multi-tensor optimizer (clip + Adam/AdamW + EMA), csrc/opt_kernels.h ---------------------------------------------
 struct rdmi_opt {
+    std::vector<OptSlot> h_slots;           // host mirror of the slot table (rdmi_opt_update_slots uploads from here)
     int nslots = 0, nchunks = 0;
     OptSlot* d_slots = nullptr; OptChunk* d_chunks = nullptr; int* d_first = nullptr; float* d_partial = nullptr; float* d_norm = nullptr;
 };
@@ -2576,7 +2582,24 @@ int rdmi_opt_create(const rdmi_opt_slot* slots, int n, rdmi_opt** out) {
     if (hipMemcpy(q->d_slots, slots, (size_t)n * sizeof(OptSlot), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
     if (hipMemcpy(q->d_chunks, chunks.data(), chunks.size() * sizeof(OptChunk), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
     if (hipMemcpy(q->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy");
+    q->h_slots.assign(reinterpret_cast<const OptSlot*>(slots), reinterpret_cast<const OptSlot*>(slots) + n);
     *out = q;
+    return 0;
+}
+
+// New pointers for the same tensors (same count, same element counts): e.g. the gradients of a step landed in a fresh buffer.
+// One asynchronous upload on `stream`; no allocation, no synchronisation.
+int rdmi_opt_update_slots(rdmi_opt* q, const rdmi_opt_slot* slots, int n, void* stream) {
+    if (!q || !slots) return fail("rdmi_opt_update_slots: null argument");
+    if (n != q->nslots) return fail("rdmi_opt_update_slots: %d slots, the table was created with %d", n, q->nslots);
+    const OptSlot* ns = reinterpret_cast<const OptSlot*>(slots);
+    for (int t = 0; t < n; ++t) {
+        if (ns[t].n != q->h_slots[(size_t)t].n) return fail("rdmi_opt_update_slots: slot %d changed its element count", t);
+        if (!slots[t].param || !slots[t].grad || !slots[t].exp_avg || !slots[t].exp_avg_sq) return fail("rdmi_opt_update_slots: slot %d has a null pointer", t);
+        if ((q->h_slots[(size_t)t].ema == nullptr) != (ns[t].ema == nullptr)) return fail("rdmi_opt_update_slots: slot %d gained or lost its EMA shadow", t);
+    }
+    q->h_slots.assign(ns, ns + n);
+    HIP_OK(hipMemcpyAsync(q->d_slots, q->h_slots.data(), (size_t)n * sizeof(OptSlot), hipMemcpyHostToDevice, (hipStream_t)stream));
     return 0;
 }
 

@@ -39,6 +39,19 @@ struct TrainPlan {
     SgemmArgs* d_gemm_jobs = nullptr; ColsumJob* d_col_jobs = nullptr;   // job tables of the embedding backward (64 entries each)
     std::vector<SgemmArgs> h_gemm_jobs; std::vector<ColsumJob> h_col_jobs;
     std::vector<SgemmArgs> m_gemm_jobs; std::vector<ColsumJob> m_col_jobs;   // host mirror of what the device tables hold (uploads only on change)
+    // ---- launch graphs (RDMI_TRAIN_GRAPH=0: plain launches).  The ~100 launches of the train-mode forward and the ~250 of the backward
+    //      are each recorded ONCE (on a stream of the plan, with the weight-gradient side stream forked and joined inside) and replayed
+    //      on the caller's stream by one hipGraphLaunch per step.  Everything a replay reads or writes lives at fixed addresses: the
+    //      caller's x / sigma / labels / grad_out are copied into buffers of the plan first, the dropout seed is a device word.
+    bool use_graph = true;
+    hipStream_t cap = nullptr;                            // capture stream (the caller's may be the legacy default stream, which cannot capture)
+    hipGraphExec_t fwd_exec = nullptr, bwd_exec = nullptr;
+    std::vector<unsigned long long> fwd_key, bwd_key;     // what a recorded graph depends on (batch, dropout, pointers)
+    int fwd_calls = 0, bwd_calls = 0;                     // the first call of each runs eagerly (one-time attribute / table setup happens there)
+    float *x_in = nullptr, *out_buf = nullptr, *gout_buf = nullptr, *grads_int = nullptr;   // grads_int: the flat parameter gradient the recorded backward writes
+    unsigned long long* d_seed = nullptr; unsigned long long* h_seed = nullptr; int seed_slot = 0;   // device seed word; pinned staging ring of 64
+    std::vector<PackJob> m_jobs_fwd, m_jobs_bwd;          // host mirrors of the two pack-job tables (uploaded only when a parameter pointer changed)
+    long graph_replays = 0, graph_records = 0;
 };
 
 void conv_tile_cfg(ConvArgs& a, int& cfg) {
@@ -296,6 +309,18 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     T.h_gemm_jobs.reserve(64); T.h_col_jobs.reserve(64);
     HIP_OK(hipMalloc((void**)&T.sig_copy, Mp * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.lab_copy, Mp * std::max(1, c->arch.num_classes) * sizeof(float)));
+    {
+        const size_t E = (size_t)c->H * c->W * c->arch.channels;
+        HIP_OK(hipMalloc((void**)&T.x_in, Mp * E * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.out_buf, Mp * E * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.gout_buf, Mp * E * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.grads_int, std::max<size_t>(T.ptotal, 1) * sizeof(float)));
+        HIP_OK(hipMalloc((void**)&T.d_seed, 64));
+        HIP_OK(hipMemset(T.d_seed, 0, 64));
+        HIP_OK(hipHostMalloc((void**)&T.h_seed, 64 * sizeof(unsigned long long), 0));
+        if (const char* e = getenv("RDMI_TRAIN_GRAPH")) T.use_graph = atoi(e) != 0;
+        if (T.use_graph && hipStreamCreateWithFlags(&T.cap, hipStreamNonBlocking) != hipSuccess) { T.cap = nullptr; T.use_graph = false; }
+    }
     // resolve pointers of the data-gradient convs
     for (auto& b : T.convs) {
         if (b.has_dgrad) {
@@ -332,30 +357,112 @@ int rdmi_enable_training(rdmi_ctx* c) {
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Pack-job tables follow the parameter pointers (torch keeps the storage): uploaded only when one changed; the parameter-dependent
+// pointers of the layer plan are refreshed on the host.  No launch, no synchronisation.
+int train_refresh_params(rdmi_ctx* c, TrainPlan& T, hipStream_t s) {
+    for (auto& p : c->params)
+        if (!p.ptr) return fail("parameter '%s' was never bound (rdmi_set_param)", p.name.c_str());
+    for (size_t i = 0; i < c->jobs.size(); ++i) c->jobs[i].src = c->params[(size_t)c->job_param[i]].ptr;
+    for (size_t i = 0; i < T.jobs.size(); ++i) T.jobs[i].src = c->params[(size_t)T.job_param[i]].ptr;
+    auto same = [](const std::vector<PackJob>& a, const std::vector<PackJob>& b) { return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(PackJob)) == 0); };
+    if (!same(T.m_jobs_fwd, c->jobs)) {
+        T.m_jobs_fwd = c->jobs;
+        HIP_OK(hipMemcpyAsync(c->d_jobs, T.m_jobs_fwd.data(), T.m_jobs_fwd.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    }
+    if (!T.jobs.empty() && !same(T.m_jobs_bwd, T.jobs)) {
+        T.m_jobs_bwd = T.jobs;
+        HIP_OK(hipMemcpyAsync(T.d_jobs, T.m_jobs_bwd.data(), T.m_jobs_bwd.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    }
+    for (auto& op : c->ops) {
+        if (op.kind == OP_CONV) {
+            ConvArgs& a = op.conv;
+            a.bias = P(c, op.p_bias);
+            a.bias_sc = op.p_bias_sc.empty() ? nullptr : P(c, op.p_bias_sc);
+            a.gamma = op.p_gamma.empty() ? nullptr : P(c, op.p_gamma);
+            a.beta = op.p_beta.empty() ? nullptr : P(c, op.p_beta);
+        } else { op.attn.gamma = P(c, op.p_gamma); op.attn.beta = P(c, op.p_beta); op.attn.b3 = P(c, op.p_b3); }
+    }
+    c->packed_valid = true;
+    return 0;
+}
+
+unsigned long long param_ptr_hash(const rdmi_ctx* c) {
+    unsigned long long h = 1469598103934665603ull;
+    for (auto& p : c->params) { h ^= (unsigned long long)reinterpret_cast<size_t>(p.ptr); h *= 1099511628211ull; }
+    return h;
+}
+
+// Run `body(stream)`: replay its recorded graph when `key` is unchanged, record it when it is not (from the second call on), or
+// launch it eagerly (first call, RDMI_TRAIN_GRAPH=0, or a runtime that cannot capture).
+template <class Body>
+int run_recorded(TrainPlan& T, hipGraphExec_t& exec, std::vector<unsigned long long>& have, const std::vector<unsigned long long>& key, int& calls,
+                 hipStream_t s, Body&& body) {
+    if (T.use_graph && exec && have == key) { ++T.graph_replays; HIP_OK(hipGraphLaunch(exec, s)); return 0; }
+    if (!T.use_graph || calls++ < 1) return body(s);
+    if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; have.clear(); }
+    // everything already enqueued on the caller's stream (input copies, seed) must precede the graph: the graph is launched on `s`
+    if (hipStreamBeginCapture(T.cap, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); T.use_graph = false; return body(s); }
+    const int e = body(T.cap);
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(T.cap, &g);
+    if (e) { if (g) (void)hipGraphDestroy(g); return e; }
+    if (ce != hipSuccess || !g) { (void)hipGetLastError(); T.use_graph = false; return body(s); }
+    const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) { (void)hipGetLastError(); exec = nullptr; T.use_graph = false; return body(s); }
+    have = key; ++T.graph_records;
+    HIP_OK(hipGraphLaunch(exec, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 // Train-mode forward: layer plan, every activation kept, Dropout_0 (p) on the input of every Conv_1.
 int rdmi_train_forward(rdmi_ctx* c, const float* x, const float* sigma, const float* labels, float* out, int B, float dropout_p,
                        uint64_t seed, void* stream) {
     if (!c || !x || !sigma || !out) return fail("null argument");
     TrainPlan* T = get_train(c);
     if (!T) return fail("call rdmi_enable_training first");
+    if (B < 1 || B > c->max_batch) return fail("batch %d outside [1, %d]", B, c->max_batch);
     hipStream_t s = (hipStream_t)stream;
-    if (int e = do_repack(c, s)) return e;
+    if (int e = train_refresh_params(c, *T, s)) return e;
     T->drop_p = dropout_p; T->seed = seed; T->last_B = B;
-    for (size_t oi = 0; oi < c->ops.size(); ++oi) {
-        Op& op = c->ops[oi];
-        if (op.kind == OP_CONV) { op.conv.drop_p = op.dropout ? dropout_p : 0.f; op.conv.drop_seed = seed; op.conv.op_id = (uint32_t)oi; }
-    }
+    // inputs -> fixed addresses; the seed -> the device word the kernels read
+    const size_t E = (size_t)c->H * c->W * c->arch.channels;
+    HIP_OK(hipMemcpyAsync(T->x_in, x, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_OK(hipMemcpyAsync(T->sig_copy, sigma, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (labels) HIP_OK(hipMemcpyAsync(T->lab_copy, labels, (size_t)B * c->arch.num_classes * sizeof(float), hipMemcpyDeviceToDevice, s));
-    FwdIn f{x, 0, sigma, 0, 0.f, 0, 0.f, 0.f, labels, B, out, B};
-    const bool keep = c->use_fused;
-    c->use_fused = false;
-    c->in_train_forward = true;
-    int e = run_forward(c, f, s);
-    c->in_train_forward = false;
-    c->use_fused = keep;
-    for (auto& op : c->ops) if (op.kind == OP_CONV) op.conv.drop_p = 0.f;
-    return e;
+    T->seed_slot = (T->seed_slot + 1) & 63;
+    T->h_seed[T->seed_slot] = seed;
+    HIP_OK(hipMemcpyAsync(T->d_seed, T->h_seed + T->seed_slot, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    auto body = [&](hipStream_t ss) -> int {
+        for (size_t oi = 0; oi < c->ops.size(); ++oi) {
+            Op& op = c->ops[oi];
+            if (op.kind == OP_CONV) { op.conv.drop_p = op.dropout ? dropout_p : 0.f; op.conv.drop_seed = seed; op.conv.seed_dev = T->d_seed; op.conv.op_id = (uint32_t)oi; }
+        }
+        hipLaunchKernelGGL(pack_kernel, dim3(32, (unsigned)c->jobs.size()), dim3(RDMI_THREADS), 0, ss, (const PackJob*)c->d_jobs);
+        FwdIn f{T->x_in, 0, T->sig_copy, 0, 0.f, 0, 0.f, 0.f, labels ? T->lab_copy : nullptr, B, T->out_buf, B};
+        const bool keep = c->use_fused;
+        c->use_fused = false;
+        c->in_train_forward = true;
+        const int e = run_forward(c, f, ss);
+        c->in_train_forward = false;
+        c->use_fused = keep;
+        for (auto& op : c->ops) if (op.kind == OP_CONV) { op.conv.drop_p = 0.f; op.conv.seed_dev = nullptr; }
+        return e;
+    };
+    unsigned pb; std::memcpy(&pb, &dropout_p, 4);
+    const std::vector<unsigned long long> key{(unsigned long long)B, pb, labels ? 1ull : 0ull, param_ptr_hash(c), c->profiling ? 1ull : 0ull};
+    if (c->profiling) { if (int e = body(s)) return e; }         // per-launch events: never from a recorded graph
+    else if (int e = run_recorded(*T, T->fwd_exec, T->fwd_key, key, T->fwd_calls, s, body)) return e;
+    HIP_OK(hipMemcpyAsync(out, T->out_buf, (size_t)B * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
 }
 
 // Backward of the last rdmi_train_forward: grad_out [B,1,H,W] -> every parameter gradient, written (not accumulated) into
@@ -366,16 +473,22 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
     if (!Tp) return fail("call rdmi_enable_training first");
     TrainPlan& T = *Tp;
     if (grads_numel != T.ptotal) return fail("grads buffer holds %zu floats, the model has %zu parameters", grads_numel, T.ptotal);
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s0 = (hipStream_t)stream;
     const int NB = T.last_B;
     const size_t NBmax = (size_t)c->max_batch;
     const int sbf = c->arch.compute_dtype == 1;      // bf16 activation workspace and scratch tensors
-    // transposed packs
-    for (size_t i = 0; i < T.jobs.size(); ++i) T.jobs[i].src = c->params[(size_t)T.job_param[i]].ptr;
-    if (!T.jobs.empty()) {
-        HIP_OK(hipMemcpyAsync(T.d_jobs, T.jobs.data(), T.jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(pack_kernel, dim3(32, (unsigned)T.jobs.size()), dim3(RDMI_THREADS), 0, s, (const PackJob*)T.d_jobs);
+    if (int e = train_refresh_params(c, T, s0)) return e;
+    x = T.x_in;                                      // the forward's own copy of the input (fixed address)
+    {
+        const size_t E = (size_t)c->H * c->W * c->arch.channels;
+        HIP_OK(hipMemcpyAsync(T.gout_buf, grad_out, (size_t)NB * E * sizeof(float), hipMemcpyDeviceToDevice, s0));
+        grad_out = T.gout_buf;
     }
+    float* const grads_caller = grads_flat;
+    grads_flat = T.grads_int;                        // fixed address: the recorded launches write here, one copy hands the result to the caller
+    auto body = [&](hipStream_t s) -> int {
+    // transposed packs
+    if (!T.jobs.empty()) hipLaunchKernelGGL(pack_kernel, dim3(32, (unsigned)T.jobs.size()), dim3(RDMI_THREADS), 0, s, (const PackJob*)T.d_jobs);
     HIP_OK(hipMemsetAsync(grads_flat, 0, T.ptotal * sizeof(float), s));
     HIP_OK(hipMemsetAsync(T.gws, 0, c->ws_per_sample * NBmax * sizeof(float), s));
     HIP_OK(hipMemsetAsync(T.gdense, 0, (size_t)pad16(c->max_batch) * c->dense_total * sizeof(float), s));
@@ -446,7 +559,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.GA = T.GA; g.ACT = ACTp; g.a_bf16 = op.a_is_input ? 0 : sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
             g.has_gn = b.has_gn ? 1 : 0; g.G = fa.G; g.eps = fa.eps;
             if (b.has_gn) { g.gamma = fa.gamma; g.beta = fa.beta; g.dgamma = pgrad(b.p_gamma); g.dbeta = pgrad(b.p_beta); }
-            g.drop_p = op.dropout ? T.drop_p : 0.f; g.seed = T.seed; g.op_id = (uint32_t)oi;
+            g.drop_p = op.dropout ? T.drop_p : 0.f; g.seed = T.seed; g.seed_dev = T.d_seed; g.op_id = (uint32_t)oi;
             if (b.has_dgrad) {
                 g.gA = gptr(op.tA); g.gB = gptr(op.tB);
                 if (b.has_invA) { g.inv_start = T.d_int + b.invA_start; g.inv_list = T.d_int + b.invA_list; }
@@ -594,6 +707,20 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
     }
     if (T.two_streams)                                      // join: the caller's stream continues after the last weight gradients
         for (int p = 0; p < 2; ++p) if (done_rec[p]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[p], 0));
+    return 0;
+    };   // body
+    unsigned pb; std::memcpy(&pb, &T.drop_p, 4);
+    const std::vector<unsigned long long> key{(unsigned long long)NB, pb, param_ptr_hash(c)};
+    if (int e = run_recorded(T, T.bwd_exec, T.bwd_key, key, T.bwd_calls, s0, body)) return e;
+    HIP_OK(hipMemcpyAsync(grads_caller, T.grads_int, T.ptotal * sizeof(float), hipMemcpyDeviceToDevice, s0));
+    return 0;
+}
+
+// Diagnostic: how often the training step's launch graphs were recorded and replayed (tests: the recorded path is what runs).
+int rdmi_train_graph_stats(rdmi_ctx* c, long* records, long* replays) {
+    TrainPlan* T = c ? get_train(c) : nullptr;
+    if (!T || !records || !replays) return fail("no training plan");
+    *records = T->graph_records; *replays = T->graph_replays;
     return 0;
 }
 

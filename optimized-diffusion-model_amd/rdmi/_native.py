@@ -69,11 +69,13 @@ _PROTOS = {
     'rdmi_enable_training': ([C.c_void_p], C.c_int),
     'rdmi_train_forward': ([C.c_void_p, _F, _F, _F, _F, C.c_int, C.c_float, C.c_uint64, C.c_void_p], C.c_int),
     'rdmi_backward': ([C.c_void_p, _F, _F, C.c_size_t, _F, C.c_void_p], C.c_int),
+    'rdmi_train_graph_stats': ([C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)], C.c_int),
     'rdmi_em_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
     'rdmi_langevin_update': ([_F, _F, _F, _F, _F, _F, C.c_int, C.c_int, C.c_float, C.c_void_p], C.c_int),
     'rdmi_pc_sample': ([C.c_void_p, _F, _F, _F, _F, _F, _F, C.c_int, C.POINTER(PcOpts), C.c_uint, C.c_void_p], C.c_int),
     'rdmi_ode_sample': ([C.c_void_p, _F, _F, _F, C.c_int, C.POINTER(OdeOpts), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint, C.c_void_p], C.c_int),
     'rdmi_opt_create': ([C.POINTER(OptSlot), C.c_int, C.POINTER(C.c_void_p)], C.c_int),
+    'rdmi_opt_update_slots': ([C.c_void_p, C.POINTER(OptSlot), C.c_int, C.c_void_p], C.c_int),
     'rdmi_opt_step': ([C.c_void_p, C.POINTER(OptHyper), _F, C.c_void_p], C.c_int),
     'rdmi_opt_destroy': ([C.c_void_p], C.c_int),
     'rdmi_get_tap': ([C.c_void_p, C.c_char_p, _F, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -225,6 +227,12 @@ class Context:
         with self._guard():
             check(lib().rdmi_backward(self._h, ptr(grad_out), ptr(grads_flat), grads_flat.numel(), ptr(x), stream_of(x)))
 
+    def train_graph_stats(self):
+        """(recordings, replays) of the training step's launch graphs."""
+        a, b = C.c_long(), C.c_long()
+        check(lib().rdmi_train_graph_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def pc_sample(self, x, labels, weight, noise, trace, teacher, opts, flags=0):
         with self._guard():
             check(lib().rdmi_pc_sample(self._h, ptr(x), ptr(labels), ptr(weight), ptr(noise), ptr(trace), ptr(teacher),
@@ -286,7 +294,9 @@ class OptPlan:
         self.device = torch.device(device)
         self.ptrs = tuple(t.data_ptr() for ts in (params, grads, exp_avgs, exp_avg_sqs, emas or ()) for t in ts)
         n = len(params)
-        tab = (OptSlot * n)()
+        self.n, self.has_ema = n, bool(emas)
+        self.numels = [p.numel() for p in params]
+        tab = self._tab = (OptSlot * n)()
         for i in range(n):
             for t in (params[i], grads[i], exp_avgs[i], exp_avg_sqs[i]) + ((emas[i],) if emas else ()):
                 assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == params[i].numel()
@@ -300,6 +310,15 @@ class OptPlan:
         with self._guard():
             check(lib().rdmi_opt_create(tab, n, C.byref(self._h)))
         self._stream_of = params[0]
+
+    def update_grads(self, grads):
+        """The gradients of this step live at new addresses: refresh that column of the table with one asynchronous upload."""
+        tab = self._tab
+        for i, g in enumerate(grads):
+            assert g.dtype == torch.float32 and g.is_contiguous() and g.numel() == self.numels[i]
+            tab[i].grad = g.data_ptr()
+        with self._guard():
+            check(self._owner.rdmi_opt_update_slots(self._h, tab, self.n, stream_of(self._stream_of)))
 
     def _guard(self):
         return torch.cuda.device(self.device) if self.device.type == 'cuda' else _Null()

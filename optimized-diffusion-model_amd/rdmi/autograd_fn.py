@@ -12,7 +12,12 @@ from . import _native
 class _NCSNppFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, sigma, labels, *params):
-        tctx = model.train_context(x.shape[0], x.shape[2], x.shape[3], x.device)
+        object.__setattr__(model, '_plist_now', list(params))          # this call's parameter walk, reused by the binding check
+        try:
+            tctx = model.train_context(x.shape[0], x.shape[2], x.shape[3], x.device)
+        finally:
+            object.__setattr__(model, '_plist_now', None)
+        ctx.plist = params
         out = torch.empty_like(x)
         p = float(model.dropout) if model.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
@@ -25,15 +30,15 @@ class _NCSNppFn(torch.autograd.Function):
     def backward(ctx, gout):
         (x,) = ctx.saved_tensors
         model = ctx.model
-        plist = list(model.parameters())
-        total = sum(p.numel() for p in plist)
+        plist = ctx.plist
+        total = getattr(model, '_n_param_elems', None)
+        if total is None:
+            total = model._n_param_elems = sum(p.numel() for p in plist)
         flat = torch.empty(total, dtype=torch.float32, device=x.device)
         ctx.tctx.backward(gout.contiguous().float(), flat, x)
-        grads, off = [], 0
-        for p in plist:
-            n = p.numel()
-            grads.append(flat[off:off + n].view_as(p) if p.requires_grad else None)
-            off += n
+        # one C++ call makes the 260 views (fresh tensor objects: autograd adopts them as .grad without a copy)
+        views = torch._utils._unflatten_dense_tensors(flat, plist)
+        grads = [v if p.requires_grad else None for v, p in zip(views, plist)]
         return (None, None, None, None, *grads)
 
 

@@ -16,6 +16,8 @@ What runs where (round 1):
 The reference's per-call NaN hooks (RD/losses.py:95-104) are deliberately not reproduced: they leak one hook per
 parameter per call and slow training from 0.5 s to 38 s per step.
 """
+import inspect
+
 import numpy as np
 import torch
 import torch.optim as optim
@@ -39,15 +41,66 @@ class _FusedStep:
                     return False
         return len(self.param_groups) == 1
 
+    # ---- steady-state bookkeeping.  After one full (slow) pass the lists below are kept: a step then costs one sweep of data_ptr()
+    #      calls to prove nothing moved, instead of rebuilding five lists of 260 tensors and a device table.
+    _fast = None
+    _pending_steps = 0            # per-parameter state['step'] tensors are advanced lazily (state_dict / load_state_dict / step flush them)
+
+    def _flush_steps(self):
+        if self._pending_steps and self._fast is not None:
+            torch._foreach_add_([self.state[p]['step'] for p in self._fast['params']], float(self._pending_steps))
+        self._pending_steps = 0
+
+    def state_dict(self, *a, **k):
+        self._flush_steps()
+        return super().state_dict(*a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._flush_steps()
+        self._fast = None
+        return super().load_state_dict(*a, **k)
+
+    def step(self, *a, **k):
+        self._flush_steps()
+        self._fast = None
+        return super().step(*a, **k)
+
+    def add_param_group(self, *a, **k):
+        self._fast = None
+        return super().add_param_group(*a, **k)
+
     def fused_step(self, grad_clip=-1.0, ema=None):
         """Returns True when the EMA update was done here too (the caller then skips ema.update)."""
         group = self.param_groups[0]
+        f = self._fast
+        if f is not None and f['group_params'] is group['params'] and (ema is f['ema'] or f['ema'] is None and ema is None):
+            params = f['params']
+            grads = [p.grad for p in params]
+            # (`None not in grads` would call Tensor.__eq__ 260 times: 2.6 ms)
+            if (all(g is not None for g in grads) and [p.data_ptr() for p in params] == f['pptr']
+                    and (f['ema'] is None or (ema.shadow_params is f['shadow_list'] and ema.shadow_params[0].data_ptr() == f['e0']))
+                    and self.state[params[0]]['exp_avg'].data_ptr() == f['m0']
+                    and sum(1 for q in group['params'] if q.grad is not None) == f['n']):
+                gptr = [g.data_ptr() for g in grads]
+                if gptr != f['gptr']:
+                    if not all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):
+                        f = None
+                    else:
+                        f['plan'].update_grads(grads)
+                        f['gptr'] = gptr
+                if f is not None:
+                    return self._launch(f['plan'], group, f['t0'] + self._pending_steps + 1, grad_clip, ema if f['ema'] is not None else None, counted=True)
+        self._flush_steps()
+        self._fast = None
         params = [p for p in group['params'] if p.grad is not None]
         if not params:
             return False
+        req = [q for q in group['params'] if q.requires_grad]
         if ema is not None:                                   # shadow list is over requires_grad parameters, in order
-            shadow = {id(p): s for p, s in zip([q for q in group['params'] if q.requires_grad], ema.shadow_params)}
-            if len(ema.shadow_params) != sum(1 for q in group['params'] if q.requires_grad) or any(id(p) not in shadow for p in params):
+            shadow = {id(p): s for p, s in zip(req, ema.shadow_params)}
+            # the EMA is folded in only when this step touches EVERY shadowed parameter (ema.update relaxes all of them,
+            # RD/models/ema.py:32-52); otherwise the caller runs ema.update itself
+            if len(ema.shadow_params) != len(req) or len(params) != len(req) or any(id(p) not in shadow for p in params):
                 ema = None
         for p in params:                                       # lazy state init, as torch.optim.Adam._init_group
             st = self.state[p]
@@ -68,7 +121,16 @@ class _FusedStep:
             if plan is not None:
                 plan.close()
             plan = self._plan = _native.OptPlan([p.data for p in params], grads, ms, vs, es, params[0].device)
-        t = int(self.state[params[0]]['step']) + 1
+        t0 = int(self.state[params[0]]['step'])
+        if any(int(self.state[p]['step']) != t0 for p in params):
+            raise RuntimeError('fused_step: parameters are at different optimizer steps (one bias correction serves all tensors); '
+                               'use optimizer.step() for this state')
+        self._fast = dict(group_params=group['params'], params=params, n=len(params), nreq_grad=len(params), ema=ema,
+                          shadow_list=ema.shadow_params if ema is not None else None, e0=es[0].data_ptr() if es else 0,
+                          pptr=[p.data_ptr() for p in params], gptr=[g.data_ptr() for g in grads], m0=ms[0].data_ptr(), plan=plan, t0=t0)
+        return self._launch(plan, group, t0 + 1, grad_clip, ema, counted=True)
+
+    def _launch(self, plan, group, t, grad_clip, ema, counted):
         h = _native.OptHyper()
         b1, b2 = group['betas']
         h.lr, h.beta1, h.beta2, h.eps, h.weight_decay = group['lr'], b1, b2, group['eps'], group['weight_decay']
@@ -77,9 +139,9 @@ class _FusedStep:
         if ema is not None:
             h.ema_decay_d = float(ema.next_decay())
         plan.step(h)
-        # every parameter keeps its OWN step tensor (torch's layout: a checkpoint preserves aliasing, and a torch.optim.Adam
-        # that loaded shared step tensors would advance them once per parameter)
-        torch._foreach_add_([self.state[p]['step'] for p in params], 1.0)
+        # every parameter keeps its OWN step tensor (torch's layout: a checkpoint preserves aliasing, and a torch.optim.Adam that loaded
+        # shared step tensors would advance them once per parameter); they are advanced lazily, see _flush_steps
+        self._pending_steps += 1
         return ema is not None
 
 
@@ -159,6 +221,13 @@ def get_sde_loss_fn(sde, train, reduce_mean=True, likelihood_weighting=True, eps
 def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, likelihood_weighting=False):
     """RD/losses.py:110-160.  step_fn(state, batch, class_labels=None) -> loss."""
     loss_fn = get_sde_loss_fn(sde, train, reduce_mean=reduce_mean, likelihood_weighting=likelihood_weighting)
+    takes_ema = False                               # decided ONCE from the signature: an exception raised inside optimize_fn is never retried
+    if optimize_fn is not None:
+        try:
+            ps = inspect.signature(optimize_fn).parameters
+            takes_ema = 'ema' in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
+        except (TypeError, ValueError):
+            takes_ema = False
 
     def step_fn(state, batch, class_labels=None):
         model = state['model']
@@ -170,9 +239,9 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, likelihood_weig
                 loss.backward()
             else:                                   # RD/losses.py:143-146 (the HIP backward is linear in the incoming gradient)
                 state['scaler'].scale(loss).backward()
-            try:
+            if takes_ema:
                 ema_done = optimize_fn(optimizer, model.parameters(), step=state['step'], scaler=state['scaler'], ema=state['ema'])
-            except TypeError:                       # a user-supplied optimize_fn with the reference's exact signature
+            else:                                   # a user-supplied optimize_fn with the reference's exact signature
                 ema_done = optimize_fn(optimizer, model.parameters(), step=state['step'], scaler=state['scaler'])
             state['step'] += 1
             if not ema_done:

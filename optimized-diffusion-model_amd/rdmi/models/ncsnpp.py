@@ -120,8 +120,9 @@ class NCSNpp(nn.Module):
         self.compute_dtype = str(getattr(m, 'compute_dtype', 'f32'))
         if self.compute_dtype not in ('f32', 'bf16'):
             raise NotImplementedError(f'compute_dtype {self.compute_dtype!r}: f32 or bf16')
-        # 'bf16': the TRAINING step's convolutions (forward, data gradient) take bf16 MFMA operands from bf16 weight copies; fp32 master
-        # weights, fp32 accumulation, fp32 optimizer (BASELINE config #4).  Sampling / evaluation are not affected.
+        # 'bf16': the TRAINING step's contractions (forward, data gradient AND weight gradient) take bf16 MFMA operands from bf16 weight
+        # copies, and the activations the forward keeps / the backward's scratch tensors are stored as bf16; fp32 master weights, fp32
+        # accumulation, fp32 gradients and optimizer (BASELINE config #4).  Sampling / evaluation are not affected.
         self.train_dtype = str(getattr(m, 'train_dtype', 'f32'))
         if self.train_dtype not in ('f32', 'bf16'):
             raise NotImplementedError(f'train_dtype {self.train_dtype!r}: f32 or bf16')
@@ -191,20 +192,32 @@ class NCSNpp(nn.Module):
         device = torch.device(device)
         key = (str(device), H, W)
         ctx = self._ctx.get(key)
-        if ctx is None or ctx.max_batch < model_batch:
+        if ctx is None or ctx.max_batch < model_batch or getattr(ctx, 'compute_dtype', self.compute_dtype) != self.compute_dtype:
             if ctx is not None:
                 ctx.close()
             ctx = _native.Context(self._arch(), max(model_batch, 16), H, W, device)
+            ctx.compute_dtype = self.compute_dtype      # a plan is built for ONE dtype: changing model.compute_dtype rebuilds it
             self._ctx[key] = ctx
-        ctx.bind((n, t) for n, t in self.state_dict(keep_vars=True).items())
+        ctx.bind(self._named_tensors())
         return ctx
+
+    def _named_tensors(self):
+        """(name, tensor) of every parameter in state_dict order, cached: state_dict() walks all 184 modules (0.4 ms per call).  The
+        tensors are looked up again whenever the module tree's parameter objects changed (load_state_dict copies in place and keeps
+        them; .to() / ._apply() on a CPU->GPU move replaces .data, which bind() sees as a new pointer)."""
+        cache = getattr(self, '_nt_cache', None)
+        plist = self._plist_now if getattr(self, '_plist_now', None) is not None else list(self.parameters())
+        if cache is None or len(cache[0]) != len(plist) or any(a is not b for a, b in zip(cache[0], plist)):
+            cache = (plist, list(self.state_dict(keep_vars=True).items()))
+            object.__setattr__(self, '_nt_cache', cache)
+        return cache[1]
 
     def train_context(self, model_batch, H, W, device):
         """A dedicated rdmi_ctx for training (layer plan, per-tensor activation storage, gradient workspace)."""
         device = torch.device(device)
         key = ('train', str(device), H, W)
         ctx = self._ctx.get(key)
-        if ctx is None or ctx.max_batch < model_batch:
+        if ctx is None or ctx.max_batch < model_batch or ctx.train_dtype != self.train_dtype:
             if ctx is not None:
                 ctx.close()
             arch = self._arch()
@@ -214,7 +227,7 @@ class NCSNpp(nn.Module):
             ctx.enable_training()
             ctx.train_dtype = self.train_dtype
             self._ctx[key] = ctx
-        ctx.bind((n, t) for n, t in self.state_dict(keep_vars=True).items())
+        ctx.bind(self._named_tensors())
         return ctx
 
     def _prep(self, x):

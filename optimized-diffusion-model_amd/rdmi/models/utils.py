@@ -49,7 +49,8 @@ def get_model_fn(model, train=False):
     on every call as a side effect."""
 
     def model_fn(x, time_cond, class_labels=None):
-        model.train() if train else model.eval()
+        if model.training != bool(train):          # (Module.train() walks every submodule: only when the mode really changes)
+            model.train() if train else model.eval()
         return model(x, time_cond, class_labels=class_labels)
 
     return model_fn

@@ -4,9 +4,14 @@
 rdmi model and a file written here loads into the reference.
 
 Loading is restricted to `torch.load(weights_only=True)`: tensors and plain containers only, nothing in the file is
-executed.  The reference stores its omegaconf `config` object in the file; a file that carries one is refused by that
-loader with a clear message (re-save it without the config entry where omegaconf is available).  `save_checkpoint`
-writes the config as a plain nested dict for the same reason.
+executed.  The reference stores its omegaconf `config` object in the file (RD/utils.py:85).  Such a file still loads here
+WITHOUT omegaconf and without running anything from it: the names of the globals the pickle refers to are read with
+`torch.serialization.get_unsafe_globals_in_checkpoint` (no unpickling), every `omegaconf.*` class among them is mapped to an
+INERT stand-in (a class with no behaviour that only records the state the pickle hands it), `typing.Any` / `builtins.dict` /
+`builtins.list` map to themselves, and any other name makes the load fail with the list of offenders.  The stand-in graph is
+then flattened to plain dicts / lists / scalars, so `loaded['config']` is a nested dict.  (omegaconf is not installed in the
+build image: the flattening is tested on a file whose pickle has the same class names and state layout, written in the test --
+a file written by omegaconf itself is "parity unpinned".)  `save_checkpoint` writes the config as a plain nested dict.
 """
 import logging
 import os
@@ -26,9 +31,74 @@ def _plain(cfg):
     return str(cfg)
 
 
+class _Inert:
+    """Stand-in for a class of a module that is absent here (omegaconf.*): no behaviour, it only keeps what the pickle gives it."""
+
+    def __new__(cls, *args, **kwargs):
+        return object.__new__(cls)
+
+    def __init__(self, *args, **kwargs):
+        self._inert_args = args
+
+    def __setstate__(self, state):
+        self._inert_state = state
+
+
+_HARMLESS = {'typing.Any': None, 'builtins.dict': dict, 'builtins.list': list, 'builtins.tuple': tuple, 'builtins.int': int,
+             'builtins.float': float, 'builtins.str': str, 'builtins.bool': bool, 'builtins.object': object}
+
+
+def _stand_ins(names):
+    import typing
+    out, bad = [], []
+    for n in names:
+        if n.startswith('omegaconf.'):
+            mod, _, cls = n.rpartition('.')
+            out.append((type(cls, (_Inert,), {'__module__': mod}), n))
+        elif n in _HARMLESS:
+            out.append((typing.Any if n == 'typing.Any' else _HARMLESS[n], n))
+        else:
+            bad.append(n)
+    return out, bad
+
+
+def _flatten(o, seen=None):
+    """Inert omegaconf stand-ins -> plain containers: a container's `_content`, a value node's `_val`; back-references (`_parent`)
+    and metadata are dropped."""
+    seen = set() if seen is None else seen
+    if isinstance(o, _Inert):
+        if id(o) in seen:
+            return None
+        seen.add(id(o))
+        st = getattr(o, '_inert_state', None)
+        if isinstance(st, tuple):                # (dict state, slots state)
+            st = st[0] if isinstance(st[0], dict) else (st[1] if len(st) > 1 else None)
+        if isinstance(st, dict):
+            if '_content' in st:
+                return _flatten(st['_content'], seen)
+            if '_val' in st:
+                return _flatten(st['_val'], seen)
+        return None
+    if isinstance(o, dict):
+        return {(_flatten(k, seen) if isinstance(k, _Inert) else k): _flatten(v, seen) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_flatten(v, seen) for v in o]
+    return o
+
+
 def _load(path, device):
     try:
-        return torch.load(path, map_location=device, weights_only=True)
+        names = torch.serialization.get_unsafe_globals_in_checkpoint(path)        # reads opcodes only, unpickles nothing
+        if not names:
+            return torch.load(path, map_location=device, weights_only=True)
+        stubs, bad = _stand_ins(names)
+        if bad:
+            raise RuntimeError(f'the pickle refers to {bad}: only omegaconf.* containers (mapped to inert stand-ins) are accepted beside tensors')
+        with torch.serialization.safe_globals(stubs):
+            loaded = torch.load(path, map_location=device, weights_only=True)
+        if isinstance(loaded, dict) and 'config' in loaded:
+            loaded['config'] = _flatten(loaded['config'])
+        return loaded
     except Exception as e:   # pickle.UnpicklingError subclasses vary across torch versions
         raise RuntimeError(f'{path}: not loadable with torch.load(weights_only=True) ({type(e).__name__}: {e}); rdmi never '
                            'unpickles arbitrary objects -- re-save the checkpoint with its `config` entry as a plain dict') from e

@@ -78,6 +78,44 @@ def test_multi_sample_programs(env, golden):
         os.environ.pop('RDMI_S_MIN_WG', None)
 
 
+def test_cooperative_program(env, golden):
+    """The co-operative program on the emulator (four workgroups = four OS threads exchanging through the granule slots; consecutive
+    workgroup ids form a group there): recorded forward, ragged batches (5 and 1 samples: clamped members recompute the last
+    sample), the 8x9 shape, and agreement with the single-sample program (RDMI_COOP=0)."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    g = golden('forward_9x9.npz')
+    g8 = golden('forward_8x9.npz')
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+
+    def run(envvars):
+        os.environ.update(envvars)
+        try:
+            model, _, _ = env['ge'].make_model('cpu')
+            out = []
+            for idx in ([0, 1, 2, 3, 4], [6], list(range(8))):
+                with torch.no_grad():
+                    out.append(mutils.get_score_fn(sde, model)(T(g['x'][idx]), T(g['t'][idx]), class_labels=T(g['labels'][idx])).numpy())
+            with torch.no_grad():
+                s89 = mutils.get_score_fn(sde, model)(T(g8['x'][:3]), T(g8['t'][:3]), class_labels=T(g8['labels'][:3])).numpy()
+            ctx = model._ctx[('cpu', 9, 9)]
+            assert not ctx.coop_gave_up()
+            return out, s89, ctx.path_info()
+        finally:
+            for k in envvars:
+                os.environ.pop(k, None)
+    (a5, a1, a8), a89, info = run({})
+    assert 'co-operative groups of 4 workgroups' in info, info
+    (c5, c1, c8), c89, info_c = run({'RDMI_COOP': '0'})
+    assert 'co-operative' not in info_c, info_c
+    np.testing.assert_allclose(a8, g['score'], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(a5, g['score'][:5], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(a1, g['score'][[6]], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(a89, g8['score'][:3], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(a8, c8, rtol=0, atol=3e-5)
+    assert np.array_equal(a5, a8[:5]) and np.array_equal(a1, a8[[6]])          # a sample does not depend on its group's composition
+
+
 def test_layer_plan_intermediate_activations(env, golden):
     """Every recorded reference activation (21 taps) against the layer plan's tensors."""
     from rdmi import sde_lib
@@ -427,6 +465,32 @@ def check_fused_optimizer_step_equals_torch(dev):
         torch.nn.utils.clip_grad_norm_(pb, max_norm=0.7); ob.step()
         for p, q in zip(pa, pb):
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=3e-7)
+        # a non-finite gradient poisons the WHOLE step, as torch's clamp of the clip coefficient does: not only the
+        # NaN element's own parameter
+        for p, q in zip(pa, pb):
+            p.grad, q.grad = torch.ones_like(p), torch.ones_like(q)
+        pa[1].grad[0, 0] = float('nan'); pb[1].grad[0, 0] = float('nan')
+        fn(oa, pa, step=6, ema=None)
+        torch.nn.utils.clip_grad_norm_(pb, max_norm=0.7); ob.step()
+        for p, q in zip(pa, pb):
+            assert torch.isnan(q).all() and torch.isnan(p).all()
+    # a step that leaves a shadowed parameter without gradient does NOT claim the EMA (the caller's ema.update relaxes every shadow),
+    # and an optimize_fn without the `ema` keyword (the reference's signature) is called exactly once
+    pa = [torch.nn.Parameter(torch.randn(5).to(dev)), torch.nn.Parameter(torch.randn(7).to(dev))]
+    cfg = NS(optim=NS(optimizer='Adam', lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, warmup=0, grad_clip=-1.0))
+    oa = losses.get_optimizer(cfg, pa)
+    ea = ExponentialMovingAverage(pa, 0.5)
+    pa[0].grad = torch.ones_like(pa[0])                        # pa[1] has no gradient this step
+    assert losses.optimization_manager(cfg)(oa, pa, step=0, ema=ea) is False
+    calls = []
+
+    def ref_style(optimizer, params, step, lr=1e-2, warmup=0, grad_clip=-1.0, scaler=None):
+        calls.append(step)
+        raise TypeError('raised inside optimize_fn')
+    from rdmi import sde_lib
+    stepper = losses.get_step_fn(sde_lib.RVESDE(0.01, 5, N=10), train=True, optimize_fn=ref_style)
+    import inspect
+    assert 'takes_ema' in inspect.getclosurevars(stepper).nonlocals and inspect.getclosurevars(stepper).nonlocals['takes_ema'] is False
 
 
 def test_bf16_training_step_within_bf16_tolerance(env, golden):

@@ -133,6 +133,62 @@ def test_cifar_bf16_forward_within_bf16_tolerance(env, golden):
     assert np.abs(s - s32).max() > 1e-4 * np.abs(ref).max()
 
 
+def test_cifar_bf16_cfg_score_and_pc_updates_batch8(env):
+    """The bf16 plan at a batch that exercises the tiling (B = 8 with guidance: 16 forwards per launch, flash_attn_bf16_kernel
+    over 16 x 256 positions) -- classifier-free-guidance score with per-sample weights and reflected PC updates of the REAL
+    1000-scale schedule (teacher forcing, injected noise; updates 400, 700 and 998) against the fp32 torch oracle, within the
+    stated bf16 tolerance: score 3e-2 of each sample's largest |score| (max) / 6e-3 (rms); an update 2e-5 + 3e-2 * g(t)^2/N *
+    max|score| (the reverse SDE multiplies the score error by g^2/N)."""
+    from oracle import rd_oracle as O
+    from oracle import rd_oracle_torch as OT
+    from rdmi import sampling, sde_lib
+    from rdmi.models import utils as mutils
+    dev, ge, params = env['dev'], env['ge'], env['params']
+    model, cfg, _ = ge.make_cifar_model(dev, compute_dtype='bf16')
+    pt = {k: torch.from_numpy(v) for k, v in params.items()}
+    B, N = 8, 1000
+    sde = sde_lib.RVESDE(0.01, 50, N=N)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, 32, 32, generator=g); lab = torch.zeros(B, 1); w = torch.rand(B, generator=g)
+    t = torch.rand(B, generator=g) * 0.9 + 0.05
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        s = mutils.get_cf_score_fn(sde, model, lab.to(dev), w.to(dev))(x.to(dev), t.to(dev)).cpu()
+        ref = OT.cf_score(pt, x, t, lab, w, smax=50.0, **OT.CIFAR_ARCH)
+    assert 'bf16' in model._ctx[(str(dev), 32, 32)].path_info()
+    for n in range(B):
+        d = s[n] - ref[n]
+        amp = float(ref[n].abs().max()) * (1 + 2 * float(w[n]))          # (1+w) s_c - w s_u: both halves carry bf16 rounding
+        assert float(d.abs().max()) <= 3e-2 * amp, (n, float(d.abs().max()) / amp)
+        assert float((d ** 2).mean().sqrt()) <= 6e-3 * amp, n
+    E = 3 * 32 * 32
+    noise = torch.randn(N - 1, B, E, generator=g)
+    teacher = torch.rand(N - 1, B, E, generator=g)
+    trace = torch.zeros(N - 1, B, E, device=dev)
+    fn = sampling.get_pc_sampler(sde, (B, 3, 32, 32), sampling.get_predictor('euler_maruyama'), sampling.get_corrector('none'),
+                                 sampling.get_denoiser('none'), 0.01, 1, 1e-5, dev, noise=noise.to(dev), trace=trace, teacher=teacher.to(dev))
+    _rand = torch.rand
+    torch.rand = lambda *a, **k: x.clone()
+    try:
+        xs, nfe = fn(model, weight=w.to(dev), class_labels=lab.to(dev))
+    finally:
+        torch.rand = _rand
+    assert nfe == 2 * N
+    trace = trace.cpu()
+    assert torch.isfinite(trace).all() and float(trace.min()) >= 0 and float(trace.max()) <= 1
+    ts = O.torch_linspace(1, 1e-5, N)
+    for i in (400, 700, 998):
+        x_prev = teacher[i - 1].reshape(B, 3, 32, 32)
+        tv = torch.full((B,), float(ts[i]))
+        with torch.no_grad():
+            r = OT.pc_update(pt, x_prev, tv, lab, w, noise[i].reshape(B, 3, 32, 32), N, smax=50.0, **OT.CIFAR_ARCH)
+            sc = float((OT.cf_score(pt, x_prev, tv, lab, torch.zeros(B), smax=50.0, **OT.CIFAR_ARCH).abs().max()) * 3)
+        gg = float(OT.g_of(tv[:1], smax=50.0)[0]) ** 2 / N
+        d = (trace[i].reshape(B, 3, 32, 32) - r).abs()
+        d = torch.minimum(d, 1 - d)                                        # a value reflected at the other face of the cube is the same point
+        assert float(d.max()) <= 2e-5 + 3e-2 * gg * sc, (i, float(d.max()), gg, sc)
+
+
 def test_bf16_is_refused_where_it_is_not_built(env):
     """The 9x9 GTO-Halo plans are fp32 only: asking bf16 there fails loudly instead of silently computing in fp32."""
     ge, dev = env['ge'], env['dev']

@@ -205,7 +205,8 @@ def test_headline_schedule_n1000_per_update(env, B, corr, weight):
     pt = {k: torch.from_numpy(v) for k, v in params.items()}
     w = torch.full((B,), float(weight))
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    for i in (0, 1, 15, 16, 17, 499, 997, 998):
+    # 140/141 and 986/987: the seams of the Dense_0 chunks (141 updates per GEMM launch at 2B = 256, rdmi_pc_sample)
+    for i in (0, 1, 15, 16, 17, 140, 141, 499, 986, 987, 997, 998):
         x_prev = prior if i == 0 else teacher[i - 1].reshape(B, 1, 9, 9)
         z_corr = noise[i * per].reshape(B, 1, 9, 9) if per == 2 else None
         with torch.no_grad():
@@ -214,6 +215,95 @@ def test_headline_schedule_n1000_per_update(env, B, corr, weight):
         amp = max(1.0, float(O.RVESDE(0.01, 5, N=N).g(ts[i:i + 1])[0]) ** 2 / N) * (1 + 2 * abs(weight))
         err = float((trace[i].reshape(B, 1, 9, 9) - ref).abs().max())
         assert err <= 2e-5 * amp, (i, err, amp)
+
+
+def test_philox_stream_statistics_and_indexing(env):
+    """The noise bench.py actually times: the sampler's in-kernel Philox4x32-10 + Box-Muller stream (noise=None; the reference draws
+    torch.randn_like, RD/sampling.py:200,224), read through rdmi_philox_normal.  (a) 4 M values are N(0,1): moments within 5
+    standard errors, Kolmogorov-Smirnov, 3/4/5-sigma tail counts; (b) streams of different (seed, draw, offset) are different and
+    uncorrelated; (c) a shard's draws are a slice of the whole (any alignment); (d) it IS the sampler's stream: a run with
+    noise=None is reproduced bit for bit by a run with these values injected, for both correctors and a shard offset."""
+    from scipy import stats
+    from rdmi import _native, sampling, sde_lib
+    dev, model = env['dev'], env['model']
+    n = 1 << 22
+    z = _native.philox_normal(n, 20251005, 0, 3, dev).cpu().numpy().astype(np.float64)
+    m, v = z.mean(), z.var()
+    assert abs(m) < 5 / np.sqrt(n) and abs(v - 1) < 5 * np.sqrt(2 / n), (m, v)
+    zs = (z - m) / np.sqrt(v)
+    assert abs((zs ** 3).mean()) < 5 * np.sqrt(6 / n) and abs((zs ** 4).mean() - 3) < 5 * np.sqrt(24 / n)
+    assert stats.kstest(z[:1 << 20], 'norm').pvalue > 1e-4
+    for k in (3, 4, 5):
+        expect = 2 * stats.norm.sf(k) * n
+        got = float((np.abs(z) > k).sum())
+        assert abs(got - expect) < 6 * np.sqrt(expect) + 3, (k, got, expect)
+    assert np.abs(z).max() < 7.5 and abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5 / np.sqrt(n)       # no gross tail artefacts, no lag-1 correlation
+    base = _native.philox_normal(1 << 16, 7, 0, 0, dev).cpu().numpy()
+    for seed, off, draw in ((8, 0, 0), (7, 0, 1), (7, 1 << 20, 0), (7 + (1 << 32), 0, 0)):
+        other = _native.philox_normal(1 << 16, seed, off, draw, dev).cpu().numpy()
+        assert abs(np.corrcoef(base, other)[0, 1]) < 0.02 and not np.array_equal(base, other), (seed, off, draw)
+    whole = _native.philox_normal(5000, 99, 0, 2, dev).cpu().numpy()
+    for off in (0, 1, 2, 3, 4, 81, 1001):
+        assert np.array_equal(_native.philox_normal(5000 - off, 99, off, 2, dev).cpu().numpy(), whole[off:]), off
+    B, N = 6, 5
+    sde = sde_lib.RVESDE(0.01, 5, N=N)
+    lab = torch.rand(B, 1, device=dev)
+    prior = torch.rand(B, 1, 9, 9)
+    _rand = torch.rand
+    for corr, per in (('none', 1), ('langevin', 2)):
+        for seq in (0, 37):
+            mk = lambda **kw: sampling.get_pc_sampler(sde, (B, 1, 9, 9), sampling.get_predictor('euler_maruyama'), sampling.get_corrector(corr),
+                                                      sampling.get_denoiser('none'), 0.01, 1, 1e-5, dev, **kw)
+            inj = torch.stack([_native.philox_normal(B * 81, 4242, seq * 81, d, dev) for d in range((N - 1) * per)]).reshape(-1, B, 81)
+            torch.rand = lambda *a, **k: prior.clone()
+            try:
+                xa, _ = mk(seed=4242, seq_offset=seq)(model, weight=0.3, class_labels=lab)
+                xb, _ = mk(noise=inj)(model, weight=0.3, class_labels=lab)
+            finally:
+                torch.rand = _rand
+            assert torch.equal(xa, xb), (corr, seq)
+
+
+def test_free_run_n1000_final_distribution(env):
+    """"final samples statistically".  One full headline run (N = 1000, B = 128, guidance on, corrector none) with the
+    in-kernel Philox noise against the torch oracle run from the SAME prior and labels with torch.randn noise: the two chaotic
+    free runs cannot agree sample by sample, but they sample the same distribution -- per coordinate, the means of the 128 final
+    samples agree within 4.5 standard errors (81 coordinates; P(false alarm) < 1e-3), the variances within the F(127,127) 1e-5
+    band [0.45, 2.2], and the pooled values pass a two-sample Kolmogorov-Smirnov test."""
+    from scipy import stats
+    from oracle import rd_oracle as O
+    from oracle import rd_oracle_torch as OT
+    from rdmi import sampling, sde_lib
+    dev, model, params = env['dev'], env['model'], env['params']
+    B, N = 128, 1000
+    g = torch.Generator().manual_seed(31)
+    prior = torch.rand(B, 1, 9, 9, generator=g); lab = torch.rand(B, 1, generator=g)
+    sde = sde_lib.RVESDE(0.01, 5, N=N)
+    fn = sampling.get_pc_sampler(sde, (B, 1, 9, 9), sampling.get_predictor('euler_maruyama'), sampling.get_corrector('none'),
+                                 sampling.get_denoiser('none'), 0.01, 1, 1e-5, dev, seed=77)
+    _rand = torch.rand
+    torch.rand = lambda *a, **k: prior.clone()
+    try:
+        xg, nfe = fn(model, weight=0.0, class_labels=lab.to(dev))
+    finally:
+        torch.rand = _rand
+    assert nfe == 2 * N and not model._ctx[(str(dev), 9, 9)].coop_gave_up()
+    xg = xg.cpu().numpy().reshape(B, 81).astype(np.float64)
+    assert np.isfinite(xg).all() and xg.min() >= 0 and xg.max() <= 1
+    pt = {k: torch.from_numpy(v) for k, v in params.items()}
+    ts = O.torch_linspace(1, 1e-5, N)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    x = prior.clone(); w = torch.zeros(B)
+    with torch.no_grad():
+        for i in range(N - 1):
+            x = OT.pc_update(pt, x, torch.full((B,), float(ts[i])), lab, w, torch.randn(x.shape, generator=g), N)
+    xo = x.numpy().reshape(B, 81).astype(np.float64)
+    se = np.sqrt((xg.var(0, ddof=1) + xo.var(0, ddof=1)) / B) + 1e-9
+    zsc = (xg.mean(0) - xo.mean(0)) / se
+    assert np.abs(zsc).max() < 4.5, (np.abs(zsc).max(), int(np.abs(zsc).argmax()))
+    ratio = (xg.var(0, ddof=1) + 1e-12) / (xo.var(0, ddof=1) + 1e-12)
+    assert ratio.min() > 0.45 and ratio.max() < 2.2, (ratio.min(), ratio.max())
+    assert stats.ks_2samp(xg.ravel(), xo.ravel()).pvalue > 1e-4
 
 
 def test_generic_python_loop_equals_fused(env):
@@ -308,6 +398,50 @@ def test_both_execution_plans_agree(env, golden):
     with torch.no_grad():
         s = mutils.get_score_fn(sde, m2)(T(gg['x'], dev), T(gg['t'], dev), class_labels=T(gg['labels'], dev))
     np.testing.assert_allclose(s.cpu().numpy(), gg['score'], rtol=0, atol=2e-4)
+
+
+def test_cooperative_program(env, golden):
+    """The co-operative program (default up to one wave of workgroups: groups of four CUs share the 2x2 level and the bottleneck,
+    column-sliced convs + granule all-gathers) against the single-sample program (RDMI_COOP=0) and the reference's
+    recorded forward: B = 128 with guidance (256 workgroups = 64 groups), a ragged batch (5 samples: two groups, three clamped
+    members), groups whose members sit on DIFFERENT XCDs (RDMI_COOP_STRIDE=1: the exchange is placement-independent), repeated
+    launches (slot parity / epoch tags), and no bounded wait ever gave up."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    dev, ge = env['dev'], env['ge']
+    sde = sde_lib.RVESDE(0.01, 5, N=1000)
+    gg = golden('forward_9x9.npz')
+    g = torch.Generator().manual_seed(77)
+    B = 128
+    x = torch.rand(B, 1, 9, 9, generator=g).to(dev); t = (torch.rand(B, generator=g) * 0.99 + 0.01).to(dev)
+    lab = torch.rand(B, 1, generator=g).to(dev)
+
+    def run(envvars):
+        os.environ.update(envvars)
+        try:
+            m, _, _ = ge.make_model(dev)
+            with torch.no_grad():
+                outs = [mutils.get_cf_score_fn(sde, m, lab, 0.3)(x, t) for _ in range(3)]            # three launches: both slot parities
+                s5 = mutils.get_score_fn(sde, m)(T(gg['x'][:5], dev), T(gg['t'][:5], dev), class_labels=T(gg['labels'][:5], dev))
+                s8 = mutils.get_score_fn(sde, m)(T(gg['x'], dev), T(gg['t'], dev), class_labels=T(gg['labels'], dev))
+            ctx = m._ctx[(str(dev), 9, 9)]
+            assert not ctx.coop_gave_up()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])                    # run-to-run identical
+            return outs[0].cpu().numpy(), s5.cpu().numpy(), s8.cpu().numpy(), ctx.path_info()
+        finally:
+            for k in envvars:
+                os.environ.pop(k, None)
+    a, a5, a8, info = run({})
+    assert 'co-operative groups of 4 workgroups' in info and 'id stride 8' in info, info
+    b, b5, b8, info_b = run({'RDMI_COOP_STRIDE': '1'})
+    assert 'id stride 1' in info_b, info_b
+    c, c5, c8, info_c = run({'RDMI_COOP': '0'})
+    assert 'co-operative' not in info_c, info_c
+    assert np.array_equal(a, b) and np.array_equal(a5, b5) and np.array_equal(a8, b8)               # placement changes nothing, bit for bit
+    np.testing.assert_allclose(a, c, rtol=0, atol=3e-5)                                             # K split over four wave groups: other summation order
+    np.testing.assert_allclose(a8, gg['score'], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(a5, gg['score'][:5], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(a5, a8[:5], rtol=0, atol=0)                                          # a sample does not depend on its group's composition
 
 
 def test_large_batch_many_workgroups(env):

@@ -187,3 +187,105 @@ def test_checkpoint_layout_round_trip(tmp_path, golden):
     with pytest.raises(RuntimeError, match='weights_only'):
         utils.load_denoising_model(str(tmp_path / 'ref_style.pth'), model3)
 
+
+
+def _write_reference_layout_checkpoint(path, model, opt, ema, cfg_dict):
+    """A checkpoint file in EXACTLY the layout RD/utils.py:78-86 writes, including a pickled omegaconf-style `config` object:
+    classes named omegaconf.dictconfig.DictConfig / omegaconf.listconfig.ListConfig / omegaconf.nodes.AnyNode /
+    omegaconf.base.{ContainerMetadata,Metadata} with omegaconf's state layout (_content / _val / _parent / _metadata, typing.Any and
+    builtins.dict references).  omegaconf itself is not installed here, so the classes are created under those module names only
+    while the file is written and removed again: the loader under test never sees them."""
+    import sys
+    import types
+    import typing
+    made = []
+
+    def mk(modname, clsname):
+        if modname not in sys.modules:
+            sys.modules[modname] = types.ModuleType(modname); made.append(modname)
+        cls = type(clsname, (), {'__module__': modname})
+        setattr(sys.modules[modname], clsname, cls)
+        return cls
+    for mn in ('omegaconf',):
+        if mn not in sys.modules:
+            sys.modules[mn] = types.ModuleType(mn); made.append(mn)
+    CM, MD = mk('omegaconf.base', 'ContainerMetadata'), mk('omegaconf.base', 'Metadata')
+    DC, LC, AN = mk('omegaconf.dictconfig', 'DictConfig'), mk('omegaconf.listconfig', 'ListConfig'), mk('omegaconf.nodes', 'AnyNode')
+
+    def meta(cls, obj_type, key):
+        m = cls()
+        m.__dict__.update(ref_type=typing.Any, object_type=obj_type, optional=True, key=key, flags=None)
+        if cls is CM:
+            m.__dict__.update(key_type=typing.Any, element_type=typing.Any)
+        return m
+
+    def wrap(v, parent, key):
+        if isinstance(v, dict):
+            o = DC()
+            o.__dict__.update(_metadata=meta(CM, dict, key), _parent=parent, _flags_cache=None, _content={})
+            for k, x in v.items():
+                o._content[k] = wrap(x, o, k)
+            return o
+        if isinstance(v, (list, tuple)):
+            o = LC()
+            o.__dict__.update(_metadata=meta(CM, list, key), _parent=parent, _flags_cache=None, _content=[])
+            for i, x in enumerate(v):
+                o._content.append(wrap(x, o, i))
+            return o
+        o = AN()
+        o.__dict__.update(_val=v, _parent=parent, _metadata=meta(MD, None, key))
+        return o
+    try:
+        ck = {'step': 8400, 'model': model.state_dict(), 'optimizer': opt.state_dict(), 'ema': ema.state_dict(), 'scaler': None,
+              'config': wrap(cfg_dict, None, None)}
+        torch.save(ck, path)
+    finally:
+        for mn in made:
+            sys.modules.pop(mn, None)
+        for mn in list(sys.modules):
+            if mn.startswith('omegaconf'):
+                sys.modules.pop(mn, None)
+
+
+def test_reference_layout_checkpoint_with_omegaconf_config_loads(tmp_path):
+    """SURVEY 8f N2, the reference's own files: RD/utils.py:85 stores the omegaconf config object.  It loads with
+    torch.load(weights_only=True) and inert stand-ins for the omegaconf classes (rdmi/utils.py) -- omegaconf absent, nothing of the
+    file executed -- into model / optimizer / EMA in place, and the config comes back as plain dicts; a pickle that refers to any
+    other foreign class is still refused."""
+    import sys
+    import __graft_entry__ as ge
+    from rdmi import losses, utils
+    from rdmi.models import utils as mutils
+    from rdmi.models.ema import ExponentialMovingAverage
+    cfg = ge.demo_config()
+    torch.manual_seed(3)
+    model = mutils.create_model(cfg)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    for p in model.parameters():
+        p.grad = torch.full_like(p, 2e-3)
+    opt.step(); ema.update(model.parameters())
+    cfg_dict = utils._plain(cfg)
+    path = str(tmp_path / 'checkpoint_8400.pth')
+    _write_reference_layout_checkpoint(path, model, opt, ema, cfg_dict)
+    assert not any(m.startswith('omegaconf') for m in sys.modules)
+    names = torch.serialization.get_unsafe_globals_in_checkpoint(path)
+    assert 'omegaconf.dictconfig.DictConfig' in names and 'omegaconf.nodes.AnyNode' in names
+    with pytest.raises(Exception):
+        torch.load(path, weights_only=True)                        # the plain safe loader refuses the file ...
+    torch.manual_seed(4)
+    model2 = mutils.create_model(cfg)
+    opt2 = losses.get_optimizer(cfg, model2.parameters())
+    ema2 = ExponentialMovingAverage(model2.parameters(), decay=cfg.model.ema_rate)
+    st = utils.restore_checkpoint(path, dict(optimizer=opt2, model=model2, ema=ema2, step=0, scaler=None), 'cpu')      # ... rdmi loads it
+    assert st['step'] == 8400
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))
+    assert all(torch.equal(a, b) for a, b in zip(ema.shadow_params, ema2.shadow_params)) and ema2.num_updates == ema.num_updates
+    loaded = utils._load(path, 'cpu')
+    assert loaded['config'] == cfg_dict and loaded['config']['model']['ch_mult'] == [1, 2, 2]
+    assert not any(m.startswith('omegaconf') for m in sys.modules)          # nothing was imported to do it
+    m3 = utils.load_denoising_model(path, mutils.create_model(cfg))
+    assert torch.equal(m3.state_dict()['input_conv.weight'], model.state_dict()['input_conv.weight'])
+    torch.save({'model': model.state_dict(), 'config': _NotPlain()}, str(tmp_path / 'other.pth'))
+    with pytest.raises(RuntimeError, match='only omegaconf'):
+        utils.load_denoising_model(str(tmp_path / 'other.pth'), m3)

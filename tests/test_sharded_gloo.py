@@ -1,6 +1,8 @@
 """Multi-process (gloo, world_size 2, CPU) cover of the N>1 path: rank-sharded sampling + ONE all-gather equals the
-unsharded run (corrector none), and the Langevin per-shard semantics are the documented ones.  Kernels run on the
-CPU emulator build; the collective is real torch.distributed."""
+unsharded run (corrector none); with the Langevin corrector every shard equals the run of that shard alone at batch B per rank
+(the documented semantics: the step size is a mean over the rank's own batch) and the oracle fed the shard's own Philox draws;
+the gathered batch is rank-major with labels sliced per rank.  Kernels run on the CPU emulator build; the collective
+is real torch.distributed."""
 import os
 import socket
 import sys
@@ -45,7 +47,7 @@ def _worker(rank, world, port, corr, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('corr', ['none'])
+@pytest.mark.parametrize('corr', ['none', 'langevin'])
 def test_sharded_equals_unsharded(tmp_path, emu, corr):
     world = 2
     port = _free_port()
@@ -62,4 +64,28 @@ def test_sharded_equals_unsharded(tmp_path, emu, corr):
     fn = sharded_sampling_fn(cfg, sde_lib.RVESDE(0.01, 5, N=3), (4, 1, 9, 9), 1e-5, 'cpu', seed=5, rank=0, world=1)
     torch.manual_seed(99)
     x, _ = fn(model, weight=0.0, class_labels=labels)
-    np.testing.assert_allclose(xs[0], x.numpy(), rtol=0, atol=1e-6)
+    if corr == 'none':
+        np.testing.assert_allclose(xs[0], x.numpy(), rtol=0, atol=1e-6)
+    else:
+        assert not np.allclose(xs[0], x.numpy(), atol=1e-6)      # a batch-mean step size: the global batch of 4 is NOT two batches of 2
+    # rank-major order, labels sliced per rank: rows [r*B, (r+1)*B) are rank r's shard run ALONE (same seed, stream offset r*B,
+    # prior = that slice of the global draw) -- for both correctors
+    from oracle import rd_oracle as O
+    from rdmi import _native, sampling
+    _, _, params = ge.make_model('cpu')
+    sde = sde_lib.RVESDE(0.01, 5, N=3)
+    B, per = 2, (2 if corr == 'langevin' else 1)
+    for r in range(world):
+        fn_r = sampling.get_pc_sampler(sde, (B, 1, 9, 9), sampling.get_predictor('euler_maruyama'), sampling.get_corrector(corr),
+                                       sampling.get_denoiser('none'), 0.01, 1, 1e-5, 'cpu', seed=5, shard=(r, world))
+        torch.manual_seed(99)
+        xr, _ = fn_r(model, weight=0.0, class_labels=labels[r * B:(r + 1) * B])
+        assert np.array_equal(xs[0][r * B:(r + 1) * B], xr.numpy()), r
+        # ... and that shard against the oracle on the shard's own Philox draws (element offset r*B*81) and prior slice
+        torch.manual_seed(99)
+        torch.rand(world * B, 1, 9, 9)                           # the reference's discarded first prior draw
+        prior = torch.rand(world * B, 1, 9, 9)[r * B:(r + 1) * B].numpy()
+        noises = [_native.philox_normal(B * 81, 5, r * B * 81, d, 'cpu').numpy().reshape(B, 1, 9, 9) for d in range(2 * per)]
+        xo, _ = O.pc_sampler(params, O.RVESDE(0.01, 5, N=3), prior, noises, labels[r * B:(r + 1) * B].numpy(), 0.0, eps=1e-5, snr=0.01,
+                             n_steps=1, corrector=corr)
+        assert np.abs(xr.numpy() - xo).max() < 5e-2, r             # free run over two chaotic updates (g^2/N ~ 100 amplifies 1e-5)
