@@ -25,7 +25,7 @@
 #define UW_PF_N1 4
 #endif
 #ifndef UW_PF_KS1
-#define UW_PF_KS1 9       // co-operative single-row-tile convs: a wave's K slice is 9-36 steps.  Measured: 4 and 9 equal (15.5 k cycles per 9x128 conv), 18 slower
+#define UW_PF_KS1 4       // co-operative single-row-tile convs: a wave's K slice is 9-36 steps.  Measured: 4 and 9 equal (15.5 k cycles per 9x128 conv), 18 slower
                           // (18.2 k: the whole 147 KB slice of a CU is requested before the first MFMA and arrives at the L2->CU rate, nothing overlaps)
 #endif
 #ifndef UW_PRIO
@@ -840,68 +840,81 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
 // over (fop_xchg).  Nothing else is shared: skip tensors are spilled per workgroup, GroupNorm / gather ops of concat tensors
 // run redundantly on the complete tensor.
 //
-// CONV of the co-operative low-resolution section: member m computes column tiles [2m, 2m+2) (Cout_pad = 128) for all rows.
-// The 8 waves are (column tile ct = wave & 1) x (K group kg = wave >> 1): wave (ct, kg) accumulates PARTIAL sums over K steps
-// kg, kg+4, ... for every row tile (1 at 2x2, 4 at 4x4).  Row tile i is finished by the wave with kg == i (kg == 0 when there is
-// one row tile): the other three park their partials of that tile in the destination tensor's FOREIGN columns -- dead space
-// until the exchange fills it -- and after one barrier the finisher adds the four partials in the fixed order kg = 0..3
-// (run-to-run identical) and runs the common epilogue (bias, Dense_0 row, residual, scale, fused GroupNorm) on its tile.
+// CONV of the co-operative section: member m computes column tiles [2m, 2m+2) (Cout_pad = 128) of the ONE row tile that holds the
+// four samples' 4 pixels each.  The 8 waves are (column tile ct = wave & 1) x (K group kg = wave >> 1): wave (ct, kg) accumulates a
+// PARTIAL sum over K steps kg, kg+4, ...; the kg == 0 wave finishes the tile: the other three park their partials in the
+// destination tensor's FOREIGN columns -- dead space until the exchange fills it -- and after one barrier the finisher adds the
+// four partials in the fixed order kg = 0..3 (run-to-run identical) and runs the common epilogue (bias, Dense_0 row, residual,
+// scale, fused GroupNorm) on its tile.  (The interpreter must stay inside the 64 KiB instruction cache: a four-row-tile variant for
+// the 4x4 level existed and was dropped with that level's sharing -- it did not pay)
 template <bool DIAG>
 __device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, int n_grp, int m, int wave, int lane, long long* fine) {
     const int lrow = lane & 15, kq = lane >> 4;
     const int ct = wave & 1, kg = wave >> 1;
-    const int mtiles = OPI(w, mtiles);                         // 1 or 4 (host-checked)
     const int nt = 2 * m + ct, col = nt * 16 + lrow;
     const int o_Cout = OPI(w, Cout), o_dense = OPI(w, dense_off), hw_shift = OPI(w, hw_shift);
     const float* o_bias = OPP(w, const float, bias); const float* o_bias2 = OPP(w, const float, bias2);
     const bool fused_gn = OPI(w, gn_off) >= 0;
-    const int mt_e = mtiles == 4 ? kg : 0;                     // the row tile this wave finishes ...
-    const bool finisher = mtiles == 4 || kg == 0;              // ... if it finishes one
+    const bool finisher = kg == 0;
     float add = 0.f, gmul = 1.f, gadd = 0.f;
     float dadd[4] = {0.f, 0.f, 0.f, 0.f};
     if (finisher && col < o_Cout) {                            // epilogue operands: their latency hides under the main loop
         add = ldg1(o_bias + col);
         if (o_bias2) add += ldg1(o_bias2 + col);
         if (fused_gn) { gmul = ldg1(OPP(w, const float, gamma) + col); gadd = ldg1(OPP(w, const float, beta) + col); }
-        if (o_dense >= 0) {
-            const int sl = (mt_e * 16 + kq * 4) >> hw_shift;
-            dadd[0] = ldg1(u.dense + (size_t)o_dense + (size_t)min(n_grp + sl, u.NB - 1) * u.dense_stride + col);
-        }
+        if (o_dense >= 0) dadd[0] = ldg1(u.dense + (size_t)o_dense + (size_t)min(n_grp + ((kq * 4) >> hw_shift), u.NB - 1) * u.dense_stride + col);
     }
     f32x4 acc[4];
-    if (mtiles == 4) fconv_main<DIAG, 4, 4, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
-    else fconv_main<DIAG, 1, UW_PF_KS1, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
-    // park the partials this wave does not finish: tile i of K group kg goes to foreign column block (m + ((kg - fin(i)) & 3)) & 3
+    fconv_main<DIAG, 1, UW_PF_KS1, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
+    // park the partial this wave does not finish: K group kg goes to foreign column block (m + kg) & 3
     float* const dstp = lds_f(OPI(w, dst_off));
     const int drs = OPI(w, dst_rs);
+    if (!finisher) {
+        float* p = dstp + (size_t)(kq * 4) * drs + (((m + kg) & 3) * 32 + ct * 16 + lrow);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < mtiles) {
-            const int fin = mtiles == 4 ? i : 0;
-            if (kg != fin) {
-                float* p = dstp + (size_t)(i * 16 + kq * 4) * drs + (((m + ((kg - fin) & 3)) & 3) * 32 + ct * 16 + lrow);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[r * drs] = acc[i][r];
-            }
-        }
-    lds_barrier();
-    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 fin_acc[4];
-    bool have_gn = false;
-    if (finisher) {
-        f32x4 own = mtiles == 4 ? (kg == 0 ? acc[0] : kg == 1 ? acc[1] : kg == 2 ? acc[2] : acc[3]) : acc[0];
-        f32x4 part[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {           // K group k's partial of my tile: mine from registers, the others from their parking block
-            const float* p = dstp + (size_t)(mt_e * 16 + kq * 4) * drs + (((m + ((k - kg) & 3)) & 3) * 32 + ct * 16 + lrow);
-            for (int r = 0; r < 4; ++r) part[k][r] = k == kg ? own[r] : p[r * drs];
-        }
-        fin_acc[0] = (part[0] + part[1]) + (part[2] + part[3]);
-        if (!(DIAG && (u.dbg & 256))) have_gn = fconv_epi<true>(w, u, n_grp, mt_e, 1, nt, 1, lane, add, dadd, fin_acc, ps1, ps2);
+        for (int r = 0; r < 4; ++r) p[r * drs] = acc[0][r];
     }
-    if (fused_gn) {
-        lds_barrier();
-        if (have_gn) fconv_gn_apply<true>(w, mt_e, 1, nt, 1, lane, gmul, gadd, fin_acc, ps1, ps2);
+    lds_barrier();
+    if (finisher) {
+        f32x4 part[3];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float* p = dstp + (size_t)(kq * 4) * drs + (((m + k) & 3) * 32 + ct * 16 + lrow);
+            for (int r = 0; r < 4; ++r) part[k - 1][r] = p[r * drs];
+        }
+        f32x4 v = (acc[0] + part[0]) + (part[1] + part[2]);
+        if (DIAG && (u.dbg & 256)) return;
+        // epilogue of the tile, written out here (the generic fconv_epi / fconv_gn_apply pair would cost the co-operative kernel ~5 KB of
+        // instruction cache): every row is real (16 rows = 4 samples x 4 pixels), every column is real (Cout = 128); this lane's four
+        // rows kq*4 .. +3 ARE sample kq, so a GroupNorm group's statistic (4 channels x 4 pixels) is one quad reduction in registers
+        const int o_resid = OPI(w, resid_off), o_resid_rs = OPI(w, resid_rs);
+        const float o_scale = OPF(w, scale), add_all = add + dadd[0];
+        const int row0 = kq * 4;
+        if (o_resid >= 0) {
+            const float* rp = lds_f(o_resid) + (size_t)row0 * o_resid_rs + col;
+            float rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = rp[r * o_resid_rs];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] + add_all + rv[r]) * o_scale;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (v[r] + add_all + 0.f) * o_scale;
+        }
+        if (!fused_gn || OPI(w, gn_raw) != 0) {
+            float* p = dstp + (size_t)row0 * drs + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r * drs] = v[r];
+        }
+        if (fused_gn) {
+            const float s1 = quad_sum((v[0] + v[1]) + (v[2] + v[3])), s2 = quad_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            const float mean = s1 * OPF(w, inv_cnt);
+            const float rstd = (1.0f / sqrtf(fmaxf(s2 * OPF(w, inv_cnt) - mean * mean, 0.f) + OPF(w, eps))) * gmul;
+            const int act = OPI(w, gn_act), grs = OPI(w, gn_rs);
+            float* p = lds_f(OPI(w, gn_off)) + (size_t)row0 * grs + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float y = (v[r] - mean) * rstd + gadd; p[r * grs] = act ? silu_f(y) : y; }
+        }
     }
 }
 
@@ -911,7 +924,7 @@ __device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, i
 // flag: no fence, no separate flag word, correct under any workgroup placement.  Slots alternate with the parity of the
 // exchange index: a member can be at most one exchange ahead of another (it cannot pass exchange x+1 before every member has
 // published x+1, i.e. has finished reading x), so two slots suffice.  All of a thread's loads are in flight together
-// (12 x 16 B at most); the wait is bounded: on give-up the workgroup flags the launch (UnetArgs::coop_err, *failw).
+// (3 x 16 B); the wait is bounded: on give-up the workgroup flags the launch (UnetArgs::coop_err, *failw).
 __device__ __forceinline__ void fop_xchg(const OpW& w, const UnetArgs& u, int g, int m, int tid, int* failw) {
     const int mode = OPI(w, a_hw), rows = OPI(w, rows), Cs = OPI(w, C), xi = OPI(w, xidx);
     const int d_off = OPI(w, dst_off), d_rs = OPI(w, dst_rs), s_off = OPI(w, src_off), s_rs = OPI(w, src_rs);
@@ -930,7 +943,7 @@ __device__ __forceinline__ void fop_xchg(const OpW& w, const UnetArgs& u, int g,
         return (d_off >> 2) + (j * rows + row) * d_rs + c;
     };
     typedef float f32x2 __attribute__((vector_size(8)));
-    constexpr int KMAX = 4;
+    constexpr int KMAX = 1;                                  // blocks hold at most 512 granule pairs (host-checked): one per thread
     // NOTE (ROCm 7.2 clang): __builtin_bit_cast applied DIRECTLY to a vector element (bit_cast<T>(v[i])) reads element 0 whatever i is
     // -- copy the element into a scalar first.
     // ---- publish my block (mode 1: it comes from the single-sample tensor a_off and is also copied into my rows of the destination)
@@ -1138,7 +1151,7 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
             case FOP_GN: fop_gn<MS>(cur, stat, tid, pgm, pbt, DIAG ? u.dbg : 0); break;
             case FOP_CONV:
                 if (COOP && OPI(cur, coop)) fop_conv_coop<DIAG>(cur, u, n_multi, cm, wave, lane, fine);
-                else fop_conv<DIAG, MS>(cur, u, multi ? n_multi : n, wave, lane, fine);
+                else fop_conv<DIAG, MS && !COOP>(cur, u, multi ? n_multi : n, wave, lane, fine);      // co-operative: every multi-sample conv is a coop conv
                 break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             case FOP_LOADTAB: {      // row tables of the multi-sample section: global -> their LDS block

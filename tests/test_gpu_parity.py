@@ -404,7 +404,8 @@ def test_cooperative_program(env, golden):
     """The co-operative program (default up to one wave of workgroups: groups of four CUs share the 2x2 level and the bottleneck,
     column-sliced convs + granule all-gathers) against the single-sample program (RDMI_COOP=0) and the reference's
     recorded forward: B = 128 with guidance (256 workgroups = 64 groups), a ragged batch (5 samples: two groups, three clamped
-    members), groups whose members sit on DIFFERENT XCDs (RDMI_COOP_STRIDE=1: the exchange is placement-independent), repeated
+    members), both placements of a group (default: its members on four different XCDs; RDMI_COOP_STRIDE=8: all on one -- the
+    exchange is placement-independent), repeated
     launches (slot parity / epoch tags), and no bounded wait ever gave up."""
     from rdmi import sde_lib
     from rdmi.models import utils as mutils
@@ -432,9 +433,9 @@ def test_cooperative_program(env, golden):
             for k in envvars:
                 os.environ.pop(k, None)
     a, a5, a8, info = run({})
-    assert 'co-operative groups of 4 workgroups' in info and 'id stride 8' in info, info
-    b, b5, b8, info_b = run({'RDMI_COOP_STRIDE': '1'})
-    assert 'id stride 1' in info_b, info_b
+    assert 'co-operative groups of 4 workgroups' in info and 'id stride 1' in info, info
+    b, b5, b8, info_b = run({'RDMI_COOP_STRIDE': '8'})          # a whole group on ONE XCD instead of four
+    assert 'id stride 8' in info_b, info_b
     c, c5, c8, info_c = run({'RDMI_COOP': '0'})
     assert 'co-operative' not in info_c, info_c
     assert np.array_equal(a, b) and np.array_equal(a5, b5) and np.array_equal(a8, b8)               # placement changes nothing, bit for bit
