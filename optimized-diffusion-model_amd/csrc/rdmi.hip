@@ -160,6 +160,7 @@ struct rdmi_ctx {
         FOp* d_fprog = nullptr; short* d_ftabs = nullptr; float* d_spill = nullptr; size_t spill_per_sample = 0;
         UnetArgs fargs{}; size_t fused_lds = 0;
         bool coop = false; int n_xchg = 0; unsigned long long* d_xbuf = nullptr; int* d_coop_err = nullptr; int max_nb = 0;     // co-operative program
+        bool train = false;                  // the training forward's program (stashes every layer output, applies Dropout_0): never picked for inference
     };
     // tiled plan (shapes whose samples do not fit one workgroup: csrc/tiled_kernels.h)
     struct TLaunch {
@@ -199,12 +200,15 @@ struct rdmi_ctx {
         // a batch that leaves CUs to spare at one sample per workgroup and fits the chip in ONE wave of workgroups: the co-operative
         // program (groups of four CUs share the low-resolution weights); larger batches: the program with the most samples per
         // workgroup that still fills the chip
-        if (use_coop) for (auto& q : progs) if (q.ok && q.coop && NB <= q.max_nb) return &q;
+        if (use_coop) for (auto& q : progs) if (q.ok && q.coop && !q.train && NB <= q.max_nb) return &q;
         const FusedProg* best = nullptr;
-        for (auto& q : progs) if (q.ok && !q.coop && (q.S == 1 || NB >= s_min_wg * q.S) && (!best || q.S > best->S)) best = &q;
+        for (auto& q : progs) if (q.ok && !q.coop && !q.train && (q.S == 1 || NB >= s_min_wg * q.S) && (!best || q.S > best->S)) best = &q;
         return best;
     }
     bool fused_ready() const { return !progs.empty() && progs[0].ok; }
+    float train_drop_p = 0.f; const unsigned long long* train_seed_dev = nullptr;      // set around the training forward's launch
+    int train_prog = -1;                           // index in progs of the training forward's program (-1: the layer plan runs the training forward)
+    int cur_train = 0;
     int cur_coop = 0, cur_nxchg = 0, cur_cap_n = 0; unsigned long long* cur_xbuf = nullptr; int* cur_coop_err = nullptr;      // construction state (see stash_program)
     std::map<std::string, size_t> wmap;  // packed-weight arena offsets by parameter prefix
     bool packed_valid = false;
@@ -1006,6 +1010,8 @@ struct FusedBuilder {
     struct LT { int off = -1, C = 0, H = 0, W = 0, rs = 0, bytes = 0, ns = 1; int hw() const { return H * W; } int rows() const { return ns * H * W; } };
     int S = 1;                      // samples per workgroup of the program being built
     bool coop = false;              // co-operative program: S = 4 samples per GROUP of four workgroups (unet_kernel.h: fop_conv_coop)
+    bool train = false;             // training forward: stash every layer-plan tensor, Dropout_0 in the fused GroupNorm_1 epilogues
+    std::map<std::string, int> lp_tensor, lp_op;      // layer-plan tensor / op indices by name (train)
     int n_xchg = 0;                 // exchanges emitted so far
     int xslot_granules = 0;         // largest exchanged block, in 8-byte granules
     struct PendX { bool on = false; LT t; } pendx;      // output of the last co-operative 3x3 conv: exchanged before the next op is emitted
@@ -1121,7 +1127,7 @@ struct FusedBuilder {
     FOp blank(int kind) {
         FOp o;
         std::memset(&o, 0, sizeof o);
-        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1; o.gn_off = -1; o.samp = cur_samp;
+        o.kind = kind; o.a_off = -1; o.b_off = -1; o.a_map_off = -1; o.dense_off = -1; o.resid_off = -1; o.scale = 1.f; o.src_off = -1; o.gn_off = -1; o.samp = cur_samp; o.drop_op = -1;
         return o;
     }
     int emit(const FOp& o) { flush_xchg(); c->fprog.push_back(o); return (int)c->fprog.size() - 1; }
@@ -1215,6 +1221,11 @@ struct FusedBuilder {
         p.eps = 1e-6f; p.inv_cnt = 1.0f / (float)(4 * t.hw());
         patch_param(j, F_GAMMA, pre + ".weight"); patch_param(j, F_BETA, pre + ".bias");
         ++n_gn_fused;
+        if (train && pre.size() > 12 && pre.compare(pre.size() - 12, 12, ".GroupNorm_1") == 0) {      // this activation is Conv_1's input: Dropout_0 acts on it
+            auto it = lp_op.find(pre.substr(0, pre.size() - 12));
+            if (it == lp_op.end()) fail_("training forward: no layer-plan op for " + pre);
+            else if (c->ops[(size_t)it->second].dropout) p.drop_op = it->second;
+        }
         if (p.coop) {        // the conv now also produces the activated tensor (own columns): it has to travel too
             if (pendx.on) {
                 if (src) { pendx.on = false; const int ix = emit_xchg(in, nullptr); c->fprog[(size_t)ix].src_off = t.off; c->fprog[(size_t)ix].src_rs = t.rs; }
@@ -1225,6 +1236,7 @@ struct FusedBuilder {
     }
     void gn(const LT& t, const std::string& pre, bool act, const LT* src = nullptr) {
         if (try_fuse_gn(t, pre, act, src)) return;
+        if (train && pre.size() > 12 && pre.compare(pre.size() - 12, 12, ".GroupNorm_1") == 0) fail_("training forward: " + pre + " is not folded into its conv (Dropout_0 lives in that epilogue)");
         ++n_gn_ops;
         FOp o = blank(FOP_GN);
         if (src) { o.src_off = src->off; o.src_rs = src->rs; }
@@ -1275,6 +1287,26 @@ struct FusedBuilder {
         patch_arena(idx, F_W, c->wmap.at(wkey) + w_extra_off);
         if (!bias_param.empty()) patch_param(idx, F_BIAS, bias_param); else patch_arena(idx, F_BIAS_ARENA, bias_arena);
         if (sc_src) { patch_arena(idx, F_SC0W, c->wmap.at(sc_key)); patch_param(idx, F_BIAS2, bias2_param); }
+        if (train) {                     // the layer plan keeps this conv's output under the name of its op: "<block>.Conv_0", "<block>" (Conv_1), the attention block, or the conv itself
+            std::string tn = wkey;
+            auto ends = [&](const char* suf) { const size_t n = std::strlen(suf); return tn.size() >= n && tn.compare(tn.size() - n, n, suf) == 0; };
+            if (ends(".Conv_1")) tn.resize(tn.size() - 7);
+            else if (ends(".NIN_3")) tn.resize(tn.size() - 6);
+            else if (ends(".NIN_0") || ends(".qkv3")) tn.clear();
+            else if (ends(".Conv_0") && (tn.rfind("downsample.", 0) == 0 || tn.rfind("upsample.", 0) == 0)) tn.resize(tn.size() - 7);
+            if (!tn.empty() && dst_kind == 0) {
+                auto it = lp_tensor.find(tn);
+                if (it == lp_tensor.end()) fail_("training forward: no layer-plan tensor '" + tn + "'");
+                else {
+                    const Tensor& t = c->tensors[(size_t)it->second];
+                    FOp& q = c->fprog[(size_t)idx];
+                    if (t.C != Cout || t.H * t.W != q.rows) fail_("training forward: tensor '" + tn + "' has another shape");
+                    q.stash = c->ws + t.off * (size_t)c->max_batch;
+                    q.stash_bf16 = c->arch.compute_dtype == 1 ? 1 : 0;
+                }
+            }
+            c->fprog[(size_t)idx].drop_op = -1;
+        }
         if (coop && cur_samp < 0) {      // low-resolution section of the co-operative program: column-sliced, K split over the waves
             FOp& q = c->fprog[(size_t)idx];
             q.coop = 1;
@@ -1359,7 +1391,7 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
     return out;
 }
 
-int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used, bool coop);
+int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used, bool coop, bool train);
 
 // A built program is moved out of the context's construction fields into one of these (one per samples-per-workgroup value).
 void stash_program(rdmi_ctx* c, int S) {
@@ -1368,21 +1400,23 @@ void stash_program(rdmi_ctx* c, int S) {
     q.fprog.swap(c->fprog); q.fpatch.swap(c->fpatch); q.ftabs.swap(c->ftabs); q.fdesc.swap(c->fdesc);
     q.d_fprog = c->d_fprog; q.d_ftabs = c->d_ftabs; q.d_spill = c->d_spill; q.spill_per_sample = c->spill_per_sample;
     q.fargs = c->fargs; q.fused_lds = c->fused_lds;
+    q.train = c->cur_train != 0; c->cur_train = 0;
     q.coop = c->cur_coop != 0; q.n_xchg = c->cur_nxchg; q.d_xbuf = c->cur_xbuf; q.d_coop_err = c->cur_coop_err; q.max_nb = c->cur_cap_n;
     c->cur_coop = 0; c->cur_nxchg = 0; c->cur_xbuf = nullptr; c->cur_coop_err = nullptr; c->cur_cap_n = 0;
     c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr; c->spill_per_sample = 0; c->fused_ok = false; c->fused_why.clear();
     c->progs.push_back(std::move(q));
 }
 
-int build_one_program(rdmi_ctx* c, int S, bool coop = false) {
+int build_one_program(rdmi_ctx* c, int S, bool coop = false, bool train = false) {
     int used = 0, used1 = 0;
-    if (int e = build_fused_program_pass(c, S, 8 * 1024, 24 * 1024, &used, &used1, coop)) return e;
+    if (int e = build_fused_program_pass(c, S, 8 * 1024, 24 * 1024, &used, &used1, coop, train)) return e;
     if (c->fused_ok) {   // second pass with the table region sized exactly
         for (void* p : {(void*)c->d_fprog, (void*)c->d_ftabs, (void*)c->d_spill, (void*)c->cur_xbuf, (void*)c->cur_coop_err}) if (p) (void)hipFree(p);
         c->d_fprog = nullptr; c->d_ftabs = nullptr; c->d_spill = nullptr; c->cur_xbuf = nullptr; c->cur_coop_err = nullptr;
     }
     c->fused_ok = false; c->fprog.clear(); c->fpatch.clear(); c->ftabs.clear(); c->fused_why.clear();
-    if (int e = build_fused_program_pass(c, S, (used + 63) & ~63, (used1 + 63) & ~63, &used, &used1, coop)) return e;
+    if (int e = build_fused_program_pass(c, S, (used + 63) & ~63, (used1 + 63) & ~63, &used, &used1, coop, train)) return e;
+    c->cur_train = train ? 1 : 0;
     stash_program(c, S);
     return 0;
 }
@@ -1420,11 +1454,15 @@ int build_fused_program(rdmi_ctx* c) {
     return 0;
 }
 
-int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used, bool coop) {
+int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESERVE, int* tab_used, int* tab1_used, bool coop, bool train) {
     using LT = FusedBuilder::LT;
     const rdmi_arch& a = c->arch;
     FusedBuilder b{c};
-    b.S = S; b.coop = coop;
+    b.S = S; b.coop = coop; b.train = train;
+    if (train) {
+        for (size_t i = 0; i < c->tensors.size(); ++i) b.lp_tensor[c->tensors[i].name] = (int)i;
+        for (size_t i = 0; i < c->ops.size(); ++i) b.lp_op[c->ops[i].name] = (int)i;
+    }
     const int nslot0 = coop ? 1 : S;                  // how often the full-resolution sections are emitted (co-operative: the member's own sample only)
     Layout L = build_layout(c);
     std::map<std::string, int> dense_off;
@@ -1896,6 +1934,10 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
     if (c->tiled) return run_tiled(c, f.x, f.x_mod, f.sig, f.sig_mod, f.t_is_time, f.t_scalar, f.smin, f.ratio, f.out, f.NB, f.dense_rows, s);
     // ---- the U-Net: one workgroup-resident launch (csrc/unet_kernel.h) ...
     const rdmi_ctx::FusedProg* fq = (c->use_fused && !c->debug_taps) ? c->pick(f.NB) : nullptr;
+    if (c->in_train_forward) {      // one sample per workgroup pays while the batch fits the chip in about one wave of workgroups; beyond that the layer plan (bf16 MFMA) is faster
+        static const int fused_upto = [] { const char* e = std::getenv("RDMI_TRAIN_FUSED_UPTO"); return e ? atoi(e) : 2 * std::max(resident_workgroups(), 1); }();
+        fq = (c->train_prog >= 0 && c->progs[(size_t)c->train_prog].ok && f.NB <= fused_upto) ? &c->progs[(size_t)c->train_prog] : nullptr;
+    }
     if (fq) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1904,6 +1946,7 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<false, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<true, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>((unet_wg_kernel<false, false, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
         UnetArgs ua = fq->fargs;
@@ -1920,6 +1963,12 @@ int run_forward(rdmi_ctx* c, const FwdIn& f, hipStream_t s) {
         for (auto& op : c->ops) fl += op.flops_per_sample;
         ProfScope ps(c, s, "unet_wg_kernel", fl * f.NB);
         c->last_prog = (int)(fq - c->progs.data());
+        if (fq->train) {
+            ua.drop_p = c->train_drop_p; ua.seed_dev = c->train_seed_dev;
+            hipLaunchKernelGGL((unet_wg_kernel<false, false, false, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
+            HIP_OK(hipGetLastError());
+            return 0;
+        }
         if ((ua.stamps || ua.dbg) && fq->S == 1) hipLaunchKernelGGL(unet_wg_kernel<true>, dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);   // diagnostic build
         else if ((ua.stamps || ua.dbg) && fq->coop) hipLaunchKernelGGL((unet_wg_kernel<true, true, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
         else if (fq->coop) hipLaunchKernelGGL((unet_wg_kernel<false, true, true>), dim3(nwg), dim3(UW_THREADS), fq->fused_lds, s, ua);
@@ -2085,6 +2134,9 @@ const char* rdmi_path_info(rdmi_ctx* c) {
     } else {
         s = "layers: " + std::to_string(c->ops.size()) + " launches" + (c->fused_ready() ? "" : " (fused unavailable: " + (c->progs.empty() ? std::string("not built") : c->progs[0].why) + ")");
     }
+    for (auto& q : c->progs) if (q.train && !q.ok) s += "; fused training forward unavailable (" + q.why + ")";
+    if (c->train_prog >= 0 && c->progs[(size_t)c->train_prog].ok)
+        s += "; training forward: fused program (" + std::to_string(c->progs[(size_t)c->train_prog].fprog.size()) + " ops, layer outputs stashed for the backward)";
     return s.c_str();
 }
 

@@ -52,6 +52,7 @@ struct TrainPlan {
     unsigned long long* d_seed = nullptr; unsigned long long* h_seed = nullptr; int seed_slot = 0;   // device seed word; pinned staging ring of 64
     std::vector<PackJob> m_jobs_fwd, m_jobs_bwd;          // host mirrors of the two pack-job tables (uploaded only when a parameter pointer changed)
     long graph_replays = 0, graph_records = 0;
+    unsigned long long fprog_hash = 0;                    // parameter-pointer hash the training program's descriptors were last patched for
 };
 
 void conv_tile_cfg(ConvArgs& a, int& cfg) {
@@ -354,12 +355,23 @@ int rdmi_enable_training(rdmi_ctx* c) {
     try { e = build_train_plan(c, *T); } catch (const std::exception& ex) { e = fail("training plan: %s", ex.what()); }
     if (e) { delete T; return e; }
     train_registry()[c] = T;
+    // The training forward as ONE workgroup-resident launch (the S = 1 fused program + a stash of every layer output + Dropout_0
+    // in the GroupNorm_1 epilogues) instead of ~100 layer-plan launches.  RDMI_TRAIN_FUSED=0, or a shape the planner cannot fit,
+    // keeps the layer plan's forward.
+    const char* tf = getenv("RDMI_TRAIN_FUSED");
+    if (c->fused_ready() && (!tf || atoi(tf) != 0)) {
+        if (int e2 = build_one_program(c, 1, false, true)) return e2;
+        if (c->progs.back().ok && c->progs.back().train) c->train_prog = (int)c->progs.size() - 1;
+        T->fprog_hash = 0;
+    }
     return 0;
 }
 
 }  // extern "C"
 
 namespace {
+
+unsigned long long param_ptr_hash(const rdmi_ctx* c);
 
 // Pack-job tables follow the parameter pointers (torch keeps the storage): uploaded only when one changed; the parameter-dependent
 // pointers of the layer plan are refreshed on the host.  No launch, no synchronisation.
@@ -385,6 +397,27 @@ int train_refresh_params(rdmi_ctx* c, TrainPlan& T, hipStream_t s) {
             a.gamma = op.p_gamma.empty() ? nullptr : P(c, op.p_gamma);
             a.beta = op.p_beta.empty() ? nullptr : P(c, op.p_beta);
         } else { op.attn.gamma = P(c, op.p_gamma); op.attn.beta = P(c, op.p_beta); op.attn.b3 = P(c, op.p_b3); }
+    }
+    if (c->train_prog >= 0) {
+        rdmi_ctx::FusedProg& q = c->progs[(size_t)c->train_prog];
+        const unsigned long long h = param_ptr_hash(c) | 1ull;
+        if (q.ok && T.fprog_hash != h) {
+            for (auto& f : q.fpatch) {
+                FOp& o = q.fprog[(size_t)f.op];
+                const float* p = f.param.empty() ? c->d_w + f.arena_off : P(c, f.param);
+                switch (f.field) {
+                    case FusedBuilder::F_GAMMA: o.gamma = p; break;
+                    case FusedBuilder::F_BETA: o.beta = p; break;
+                    case FusedBuilder::F_BIAS: case FusedBuilder::F_BIAS_ARENA: o.bias = p; break;
+                    case FusedBuilder::F_BIAS2: o.bias2 = p; break;
+                    case FusedBuilder::F_W: o.main_ph.w = p; break;
+                    case FusedBuilder::F_SC0W: o.sc[0].w = p; break;
+                    case FusedBuilder::F_SC1W: o.sc[1].w = p; break;
+                }
+            }
+            HIP_OK(hipMemcpyAsync(q.d_fprog, q.fprog.data(), q.fprog.size() * sizeof(FOp), hipMemcpyHostToDevice, s));
+            T.fprog_hash = h;
+        }
     }
     c->packed_valid = true;
     return 0;
@@ -449,8 +482,9 @@ int rdmi_train_forward(rdmi_ctx* c, const float* x, const float* sigma, const fl
         hipLaunchKernelGGL(pack_kernel, dim3(32, (unsigned)c->jobs.size()), dim3(RDMI_THREADS), 0, ss, (const PackJob*)c->d_jobs);
         FwdIn f{T->x_in, 0, T->sig_copy, 0, 0.f, 0, 0.f, 0.f, labels ? T->lab_copy : nullptr, B, T->out_buf, B};
         const bool keep = c->use_fused;
-        c->use_fused = false;
+        c->use_fused = false;                          // (the layer plan, unless the training program exists: run_forward looks at train_prog)
         c->in_train_forward = true;
+        c->train_drop_p = dropout_p; c->train_seed_dev = T->d_seed;
         const int e = run_forward(c, f, ss);
         c->in_train_forward = false;
         c->use_fused = keep;

@@ -107,6 +107,10 @@ struct FOp {
     //      shape travels in the same exchange).  a_hw = 1: every member owns `rows` rows ([m*rows, (m+1)*rows)) of all C columns, its
     //      own block is the single-sample tensor a_off / a_rs.  xidx: index of this exchange in the program (epoch tag and slot parity).
     int xidx;
+    // ---- training forward (UnetArgs::train, csrc/train_plan.h): the backward needs every layer's output where the layer plan keeps it
+    float* stash;                                 // CONV: global [n][rows][Cout] copy of the finished output (bias, temb, residual, scale applied; before a fused GroupNorm)
+    int stash_bf16;                               //   stored as bf16 (train_dtype = bf16)
+    int drop_op;                                  // CONV with a fused GroupNorm: >= 0: Dropout_0 on the activated output, mask keyed by (step seed, this layer-plan op index, element)
 };
 
 struct UnetArgs {
@@ -131,6 +135,7 @@ struct UnetArgs {
     int xslot;                                    // granules per member slot
     unsigned epoch_base;                          // tag of exchange x of this launch = epoch_base + x + 1 (host: advanced by the program's exchange count per launch)
     int out_elems;                                // floats per sample of the network output
+    float drop_p; const unsigned long long* seed_dev;   // training forward: dropout probability and the step's seed (device word)
     int* coop_err;                                // set to 1 by a workgroup whose bounded wait gave up (its output sample is then NaN)
 };
 
@@ -483,7 +488,7 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
 // so LDS stores stay ds_write and global stores stay global_store (a merged pointer would degrade both to flat_store).
 // Returns true when the op carries a fused GroupNorm: acc[] then holds the finished raw outputs (bias, temb, residual, scale
 // applied), this wave's partial sums are parked in LDS, and the caller runs fconv_gn_apply after a workgroup barrier.
-template <bool MS>
+template <bool MS, bool TR = false>
 __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n0, int mt0, int WM, int nt, int nmt, int lane, float add, const float (&dadd)[4],
                                           f32x4 (&acc)[4], float (&ps1)[4], float (&ps2)[4]) {
     const int lrow = lane & 15, kq = lane >> 4;
@@ -563,6 +568,21 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
                 if (i < nmt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][r] = (acc[i][r] + (add + dadd[i]) + 0.f) * o_scale;
+        }
+        if (TR && o_kind == 0) {                       // training forward: the layer's output also goes where the backward reads it
+            float* const st = OPP(w, float, stash);
+            if (st) {
+                const int sbf = OPI(w, stash_bf16);
+                const size_t sbase = (size_t)min(n0 + max(OPI_samp, 0), u.NB - 1) * o_rows * o_Cout + col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nmt) {
+                        const int row0 = (mt0 + i * WM) * 16 + kq * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (row0 + r < o_rows) stact1(st, sbase + (size_t)(row0 + r) * o_Cout, acc[i][r], sbf);
+                    }
+            }
         }
         if (o_kind == 0) {
             if (write_raw) {
@@ -647,8 +667,8 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
 
 // fused GroupNorm, part 2 (after the workgroup barrier): every lane re-reduces its column's group from the parked partials,
 // normalises the values it still holds in registers, applies the affine map (+SiLU) and writes the result to gn_off.
-template <bool MS>
-__device__ __forceinline__ void fconv_gn_apply(const OpW& w, int mt0, int WM, int nt, int nmt, int lane, float gmul, float gadd, const f32x4 (&acc)[4],
+template <bool MS, bool TR = false>
+__device__ __forceinline__ void fconv_gn_apply(const OpW& w, const UnetArgs& u, int n0, int mt0, int WM, int nt, int nmt, int lane, float gmul, float gadd, const f32x4 (&acc)[4],
                                                const float (&ps1)[4], const float (&ps2)[4]) {
     const int lrow = lane & 15, kq = lane >> 4;
     const int o_rows = OPI(w, rows), o_Cout = OPI(w, Cout), nslots = OPI(w, gn_nslots);
@@ -687,7 +707,13 @@ __device__ __forceinline__ void fconv_gn_apply(const OpW& w, int mt0, int WM, in
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float y = (acc[i][r] - mean) * rstd + gadd;
-                if (row0 + r < o_rows && col < o_Cout) dstp[(row0 + r) * rs + col] = act ? silu_f(y) : y;
+                float ya = act ? silu_f(y) : y;
+                if (TR) {                               // Dropout_0 of the next conv's input (RD/models/layerspp.py:204): the mask the layer plan and the backward use
+                    const int dop = OPI(w, drop_op);
+                    if (dop >= 0 && u.drop_p > 0.f)
+                        ya *= dropout_scale((uint64_t)*u.seed_dev, (uint32_t)dop, ((uint64_t)min(n0, u.NB - 1) * o_rows + (row0 + r)) * o_Cout + col, u.drop_p);
+                }
+                if (row0 + r < o_rows && col < o_Cout) dstp[(row0 + r) * rs + col] = ya;
             }
         }
 }
@@ -758,7 +784,7 @@ __device__ __forceinline__ void fconv_qkv(const OpW& w, const UnetArgs& u, int w
     }
 }
 
-template <bool DIAG, bool MS>
+template <bool DIAG, bool MS, bool TR = false>
 __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0, int wave, int lane, long long* fine) {
     const int ntiles = OPI(w, Cout_pad) >> 4, mtiles = OPI(w, mtiles);
     const int lWN = (ntiles >= 8 && (ntiles & 7) == 0) ? 3 : (ntiles >= 4 ? 2 : (ntiles >= 2 ? 1 : 0));      // log2 of waves along N
@@ -820,14 +846,14 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
                 default: break;
             }
             if (DIAG && (u.dbg & 256)) continue;                 // ablation: no epilogue
-            fconv_epi<MS>(w, u, n0, mt0, WM, nt, nmt, lane, add, dadd, acc, ps1, ps2);
+            fconv_epi<MS, TR>(w, u, n0, mt0, WM, nt, nmt, lane, add, dadd, acc, ps1, ps2);
             k_mt0 = mt0; k_nt = nt; k_nmt = nmt;
             if (DIAG && fine) fine[5] = clock64();
         }
     }
     if (fused_gn) {
         lds_barrier();
-        if (k_nmt > 0) fconv_gn_apply<MS>(w, k_mt0, WM, k_nt, k_nmt, lane, gmul, gadd, acc, ps1, ps2);
+        if (k_nmt > 0) fconv_gn_apply<MS, TR>(w, u, n0, k_mt0, WM, k_nt, k_nmt, lane, gmul, gadd, acc, ps1, ps2);
     }
 }
 
@@ -1095,7 +1121,8 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
 // instantiation compiles all of that away -- the interpreter has to stay inside the 64 KiB instruction cache.
 // MS = true: the program may hold multi-sample ops (S > 1 samples per workgroup); MS = false compiles every trace of that away
 // (the S = 1 program keeps its leaner code).  COOP = true (with MS): the co-operative program -- see fop_conv_coop.
-template <bool DIAG, bool MS = false, bool COOP = false>
+// TRAIN = true: the training forward -- every layer's output is also stashed for the backward, Dropout_0 is applied (fconv_epi / fconv_gn_apply).
+template <bool DIAG, bool MS = false, bool COOP = false, bool TRAIN = false>
 __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1151,7 +1178,7 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
             case FOP_GN: fop_gn<MS>(cur, stat, tid, pgm, pbt, DIAG ? u.dbg : 0); break;
             case FOP_CONV:
                 if (COOP && OPI(cur, coop)) fop_conv_coop<DIAG>(cur, u, n_multi, cm, wave, lane, fine);
-                else fop_conv<DIAG, MS && !COOP>(cur, u, multi ? n_multi : n, wave, lane, fine);      // co-operative: every multi-sample conv is a coop conv
+                else fop_conv<DIAG, MS && !COOP, TRAIN>(cur, u, multi ? n_multi : n, wave, lane, fine);      // co-operative: every multi-sample conv is a coop conv
                 break;
             case FOP_ATTN: fop_attn(cur, wave, lane); break;
             case FOP_LOADTAB: {      // row tables of the multi-sample section: global -> their LDS block
