@@ -27,7 +27,7 @@ struct TrainPlan {
     // scratch of the conv backward.  G / ACT / ACTS exist 2 * group times: the weight-gradient GEMMs of a group of ops run on the
     // side stream while the main stream already produces the next group's G / ACT into the other half (two event pairs per group).
     static constexpr int MAXSETS = 16;
-    int group = 8;                       // conv ops per group (RDMI_TRAIN_GROUP), sets = 2 * group
+    int group = 4;                       // conv ops per group (RDMI_TRAIN_GROUP), sets = 2 * group.  Measured at B = 128 bf16: 8 -> 3.76 ms, 4 -> 3.70, 2 -> 3.75, 1 -> 3.92
     float *G[MAXSETS] = {}, *ACT[MAXSETS] = {}, *ACTS[MAXSETS] = {};
     float *GA = nullptr, *GS = nullptr, *zero_bias = nullptr;
     hipStream_t side = nullptr; hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -78,7 +78,11 @@ int launch_wgrad(WgradArgs w, hipStream_t s) {
     if (w.HWv > 255 || w.HWo > 128) return fail("wgrad: image of %d -> %d pixels does not fit the staged chunk", w.HWv, w.HWo);
     w.S = wgrad_chunk(w.HWv, w.HWo);
     const int tiles = ceil_div(w.Cin, 32) * ceil_div(w.Cout, 64), chunks = ceil_div(w.NB, w.S);
-    w.ksplit = std::max(1, std::min(chunks, 512 / tiles));
+    // how many workgroups a weight-gradient launch may occupy: it runs on the side stream BESIDE the data-gradient chain, whose short
+    // kernels starve when a 512-workgroup launch holds every CU (measured: 350 us of gaps per step); fewer K splits also mean fewer
+    // atomic merges of the partial tiles (HBM write traffic).  RDMI_WGRAD_WGS overrides.
+    static const int wg_budget = [] { const char* e = getenv("RDMI_WGRAD_WGS"); return e ? std::max(1, atoi(e)) : 128; }();      // measured at B = 128 (bf16 step): 512 -> 3.86 ms, 256 / 128 -> 3.75 ms, 64 -> 4.16 ms
+    w.ksplit = std::max(1, std::min(chunks, wg_budget / tiles));
     const dim3 grid((unsigned)w.ksplit, (unsigned)ceil_div(w.Cin, 32), (unsigned)ceil_div(w.Cout, 64));
     const size_t lds = wgrad_lds_bytes(w.HWv, w.HWo, w.S, w.bf16);
     if (w.bf16) {
@@ -295,7 +299,12 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
         HIP_OK(hipEventCreateWithFlags(&T.ev_ready[p], hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&T.ev_done[p], hipEventDisableTiming));
     }
-    if (T.two_streams) HIP_OK(hipStreamCreateWithFlags(&T.side, hipStreamNonBlocking));
+    if (T.two_streams) {             // RDMI_TRAIN_SIDE_PRIO=1: lowest stream priority for the weight gradients.  Off by default: measured 8.0 ms per step
+        int lo = 0, hi = 0;          // instead of 3.9 (the low-priority queue is starved outright on this runtime, it does not merely yield)
+        const char* pe = getenv("RDMI_TRAIN_SIDE_PRIO");
+        if (pe && atoi(pe) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) { if (hipStreamCreateWithPriority(&T.side, hipStreamNonBlocking, lo) != hipSuccess) T.side = nullptr; }
+        if (!T.side) HIP_OK(hipStreamCreateWithFlags(&T.side, hipStreamNonBlocking));
+    }
     HIP_OK(hipMalloc((void**)&T.GA, maxV * NBmax * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.GS, maxS * NBmax * sizeof(float)));
     HIP_OK(hipMalloc((void**)&T.zero_bias, 1024 * sizeof(float)));

@@ -144,6 +144,8 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = *hi = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 template <class F>
 inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
