@@ -27,7 +27,9 @@ struct TrainPlan {
     // scratch of the conv backward.  G / ACT / ACTS exist 2 * group times: the weight-gradient GEMMs of a group of ops run on the
     // side stream while the main stream already produces the next group's G / ACT into the other half (two event pairs per group).
     static constexpr int MAXSETS = 16;
-    int group = 4;                       // conv ops per group (RDMI_TRAIN_GROUP), sets = 2 * group.  Measured at B = 128 bf16: 8 -> 3.76 ms, 4 -> 3.70, 2 -> 3.75, 1 -> 3.92
+    int group = 8;                       // scratch sets allocated = 2 * group (RDMI_TRAIN_GROUP); conv ops per event pair at run time: group_for(NB)
+    bool group_env = false;
+    int group_for(int NB) const { return (group_env || NB > 256) ? group : std::min(group, 4); }   // measured at B = 128 bf16: 8 -> 3.76 ms, 4 -> 3.70, 2 -> 3.75, 1 -> 3.92
     float *G[MAXSETS] = {}, *ACT[MAXSETS] = {}, *ACTS[MAXSETS] = {};
     float *GA = nullptr, *GS = nullptr, *zero_bias = nullptr;
     hipStream_t side = nullptr; hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -81,7 +83,9 @@ int launch_wgrad(WgradArgs w, hipStream_t s) {
     // how many workgroups a weight-gradient launch may occupy: it runs on the side stream BESIDE the data-gradient chain, whose short
     // kernels starve when a 512-workgroup launch holds every CU (measured: 350 us of gaps per step); fewer K splits also mean fewer
     // atomic merges of the partial tiles (HBM write traffic).  RDMI_WGRAD_WGS overrides.
-    static const int wg_budget = [] { const char* e = getenv("RDMI_WGRAD_WGS"); return e ? std::max(1, atoi(e)) : 128; }();      // measured at B = 128 (bf16 step): 512 -> 3.86 ms, 256 / 128 -> 3.75 ms, 64 -> 4.16 ms
+    static const int wg_env = [] { const char* e = getenv("RDMI_WGRAD_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
+    // measured at B = 128 (bf16 step): 512 -> 3.86 ms, 256 / 128 -> 3.75 ms, 64 -> 4.16 ms; at B = 4096 the launches are long enough to want the whole chip (512: 43 ms, 128: 48 ms)
+    const int wg_budget = wg_env ? wg_env : (w.NB <= 256 ? 128 : 512);
     w.ksplit = std::max(1, std::min(chunks, wg_budget / tiles));
     const dim3 grid((unsigned)w.ksplit, (unsigned)ceil_div(w.Cin, 32), (unsigned)ceil_div(w.Cout, 64));
     const size_t lds = wgrad_lds_bytes(w.HWv, w.HWo, w.S, w.bf16);
@@ -288,7 +292,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     HIP_OK(hipMalloc((void**)&T.d_jobs, std::max<size_t>(T.jobs.size(), 1) * sizeof(PackJob)));
     for (auto& j : T.jobs) j.dst = T.d_wb + reinterpret_cast<size_t>(j.dst);
     if (const char* e = getenv("RDMI_TRAIN_STREAMS")) T.two_streams = atoi(e) != 1;
-    if (const char* e = getenv("RDMI_TRAIN_GROUP")) T.group = std::max(1, std::min(TrainPlan::MAXSETS / 2, atoi(e)));
+    if (const char* e = getenv("RDMI_TRAIN_GROUP")) { T.group = std::max(1, std::min(TrainPlan::MAXSETS / 2, atoi(e))); T.group_env = true; }
     if (!T.two_streams) T.group = 1;
     for (int p = 0; p < 2 * T.group; ++p) {
         HIP_OK(hipMalloc((void**)&T.G[p], maxG * NBmax * sizeof(float)));
@@ -550,6 +554,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
     for (auto& b : T.convs) bmap[b.op] = &b;
 
     hipStream_t s2 = T.two_streams ? T.side : s;           // weight-gradient stream
+    const int grp = T.group_for(NB);
     bool done_rec[2] = {false, false};
     int nconv = 0;                                          // conv ops seen: set = nconv % (2 * group), group half = set / group
     std::vector<WgradArgs> pending;                         // weight gradients of the current group
@@ -582,10 +587,10 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         const ConvArgs& fa = op.conv;
         const int Cin = sp.CA + sp.CB;
         const float* gY = op.out_is_output ? grad_out : gptr(op.out_tensor);
-        const int p = nconv % (2 * T.group), half = p / T.group;
+        const int p = nconv % (2 * grp), half = p / grp;
         ++nconv;
         float* Gp = T.G[p]; float* ACTp = T.ACT[p]; float* ACTSp = T.ACTS[p];
-        if (T.two_streams && p % T.group == 0 && done_rec[half]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[half], 0));   // the group before last has left this half
+        if (T.two_streams && p % grp == 0 && done_rec[half]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[half], 0));   // the group before last has left this half
         // G = scale * gY (+ identity residual) and the bias / NIN-bias / Dense_0 gradients (column sums of G)
         hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, gY, Gp, gptr(op.tRes), fa.out_scale,
                            op.use_dense ? T.gdense : (float*)nullptr, c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout, sbf);
@@ -642,10 +647,10 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             w.bf16 = sbf; w.s_bf16 = sbf;
             pending.push_back(w);
         }
-        if (p % T.group == T.group - 1) { if (int e = flush_wgrads(half)) return e; }
+        if (p % grp == grp - 1) { if (int e = flush_wgrads(half)) return e; }
         HIP_OK(hipGetLastError());
     }
-    if (int e = flush_wgrads(((nconv - 1) % (2 * T.group)) / T.group)) return e;
+    if (int e = flush_wgrads(((nconv - 1) % (2 * grp)) / grp)) return e;
 
     // ---- embedding backward: Dense_0 (x17) -> SiLU -> [label_emb, time_mlp.2] -> SiLU -> time_mlp.0.  Independent GEMMs and
     //      bias column sums of one stage go out as one job-table launch each (tables staged in T.h_*: they live until the next call).

@@ -391,7 +391,10 @@ def check_train_w0_against_reference(out, g, nsteps, rtol_loss=2e-3):
     """Adam (bias-corrected moments, eps), clip_grad_norm_(0.5) and the EMA schedule against the reference's recorded run,
     compared as UPDATES (p_k - p_0): a no-op optimizer or EMA fails by 100 %.  Tolerance: step 1 moves every weight by
     lr * g/(|g| + 1e-8) = +-5e-4 exactly unless |g| ~ 1e-8; later steps divide by sqrt(v) of fp32 gradients that agree to
-    ~1e-4 relative, so 1 % of the largest update per tensor (elements whose gradient changes sign move by < that)."""
+    ~1e-4 relative, so 1 % of the largest update per tensor (elements whose gradient changes sign move by < that).  An element
+    whose gradient is within a few 1e-7 of zero has g / (|g| + 1e-8) of order one with an error of percents from ANY 1e-5
+    difference in the forward's rounding (round 3: the training forward is the fused kernel, whose GroupNorm variance is
+    single-pass): up to 1 % of a tensor's elements may miss the 1 % bound, none may miss 5 %."""
     for k in range(nsteps):
         np.testing.assert_allclose(out[f'loss{k}'], float(g[f'step{k}.loss']), rtol=2e-5 if k == 0 else rtol_loss)
     for n in [str(x) for x in g['watch']]:
@@ -400,10 +403,12 @@ def check_train_w0_against_reference(out, g, nsteps, rtol_loss=2e-3):
         for k in range(1, nsteps + 1):
             du, dr = out[f'p{k}'][n] - p0, g[f'p{k}.' + n] - p0
             assert np.abs(dr).max() > 1e-5, n                       # the reference really moved
-            np.testing.assert_allclose(du, dr, rtol=0, atol=0.01 * np.abs(dr).max(), err_msg=f'{n} after step {k}')
+            dev = np.abs(du - dr) / np.abs(dr).max()
+            assert dev.max() <= 0.05 and (dev > 0.01).mean() <= 0.01, (n, k, float(dev.max()), float((dev > 0.01).mean()))
             eu, er = out[f'ema{k}'][n] - p0, g[f'ema{k}.' + n] - p0
             assert np.abs(er).max() > 1e-6, n
-            np.testing.assert_allclose(eu, er, rtol=0, atol=0.01 * np.abs(er).max(), err_msg=f'EMA {n} after step {k}')
+            dev = np.abs(eu - er) / np.abs(er).max()              # the shadow follows the parameter: same outlier rule
+            assert dev.max() <= 0.05 and (dev > 0.01).mean() <= 0.01, ('EMA', n, k, float(dev.max()), float((dev > 0.01).mean()))
     assert out['state']['step'] == nsteps and out['ema'].num_updates == nsteps
 
 
