@@ -174,6 +174,7 @@ struct rdmi_ctx {
         BgemmArgs gemm{};                                                                                       // kind 2
         float* sm = nullptr; long rows_per_sample = 0; int L = 0;                                               // kind 3
         const float* tsrc = nullptr; float* tdst = nullptr; int tL = 0, tC = 0, tld = 0, tc0 = 0;               // kind 4
+        int pxA = 0, pxB = 0;                                                                                   // kind 5: pixels per full tile of each producer
         // per-sample workspace offsets (floats) of the operands, resolved to pointers by finish_tiled_plan: NONE = absent, XIN = the NHWC input copy
         static constexpr size_t NONE = (size_t)-1, XIN = (size_t)-2;
         size_t oA = NONE, oB = NONE, oStats = NONE, oResid = NONE, oOut = NONE, oC = NONE; long dA = 0, dB = 0;   // dA/dB: interior deltas of GEMM operands
@@ -532,7 +533,7 @@ int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, in
 struct TiledBuilder {
     rdmi_ctx* c; Builder& b;
     size_t top = 0;                                   // floats per sample allocated so far
-    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0; bool bf = false; };   // cs: per-tile channel sums of the producer; bf: a bf16 [HW][C] tensor (C % 64 == 0) for tconv_pre
+    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0, tile_px = 0; bool bf = false; };   // cs: per-tile channel sums of the producer; bf: a bf16 [HW][C] tensor (C % 64 == 0) for tconv_pre
     TT talloc(int C, int H, int W) { TT t; t.off = top; t.C = C; t.H = H; t.W = W; t.valid = true; top += ((size_t)C * H * W + 63) & ~(size_t)63; return t; }
     static int pad32(int a) { return (a + 31) & ~31; }
 
@@ -559,7 +560,7 @@ struct TiledBuilder {
             // statistics from the channel sums the producing convs left behind: no pass over the tensors
             rdmi_ctx::TLaunch f; f.kind = 5; f.name = name + ".stats";
             f.oA = A.cs; f.oB = B ? B->cs : rdmi_ctx::TLaunch::NONE; f.CA = A.C; f.CB = B ? B->C : 0; f.HW = A.H * A.W; f.G = G;
-            f.tL = A.tiles; f.tC = B ? B->tiles : 0; f.oStats = st.off;
+            f.tL = A.tiles; f.tC = B ? B->tiles : 0; f.pxA = A.tile_px; f.pxB = B ? B->tile_px : 0; f.oStats = st.off;
             c->tl.push_back(f);
             return st;
         }
@@ -606,7 +607,7 @@ struct TiledBuilder {
         TT out = talloc(cout, a.Ho, a.Wo);
         size_t cs_off = rdmi_ctx::TLaunch::NONE;
         if (!final_out && cout % 4 == 0) {
-            out.tiles = ceil_div(a.Ho, a.TR);
+            out.tiles = ceil_div(a.Ho, a.TR); out.tile_px = a.TR * a.Wo;
             TT cs = talloc(2 * cout * out.tiles, 1, 1);
             out.cs = cs_off = cs.off;
         }
@@ -2069,7 +2070,7 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             hipLaunchKernelGGL(gn_act_kernel, dim3((unsigned)((units + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, g);
         } else if (l.kind == 5) {
             ProfScope ps(c, s, "gn_finalize_kernel", 0);
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, l.sA, l.sB, l.CA, l.CB, l.tL, l.tC, l.HW, l.G, 1e-6f, l.stats);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, l.sA, l.sB, l.CA, l.CB, l.tL, l.tC, l.pxA, l.pxB, l.HW, l.G, 1e-6f, l.stats);
         } else if (l.kind == 3) {
             const long rows = l.rows_per_sample * NB;
             ProfScope ps(c, s, "softmax_rows_kernel", 0);

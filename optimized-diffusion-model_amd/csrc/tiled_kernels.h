@@ -33,7 +33,7 @@ struct TConvArgs {
     float out_scale;
     const float* sig; int sig_is_time, sig_mod; float smin, ratio;   // scale_by_sigma: out /= sigma[n % sig_mod] (null: off)
     float* out; int Cout, Cout_pad;
-    float* chsum;                           // null or [n][tiles per image][Cout][2]: per-channel (sum, sum of squares) of this tile's outputs,
+    float* chsum;                           // null or [n][tiles per image][Cout][2]: per-channel (sum, squared deviations about the tile mean) of this tile's outputs,
                                             // from which the consumer's GroupNorm statistics are formed (gn_finalize_kernel): no extra pass over the tensor
     int NB;
 };
@@ -175,20 +175,32 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, const f32x4 (
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rv[i][r] = rbase[off[i][r]];
         }
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f;
+        float vals[NMT][4];
 #pragma unroll
         for (int i = 0; i < NMT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = (acc[i][cc][r] + add + rv[i][r]) * scale;
-                if (ok[i][r]) { obase[off[i][r]] = v; s1 += v; s2 += v * v; }
+                vals[i][r] = v;
+                if (ok[i][r]) { obase[off[i][r]] = v; s1 += v; }
             }
-        if (a.chsum) {            // this lane's column over its rows, then over the four k-groups that hold the other rows of the tile
+        if (a.chsum) {
+            // per (sample, tile, column): the sum of the tile's outputs and their squared deviations about the TILE's own mean (no
+            // E[x^2] - mean^2 cancellation: gn_finalize_kernel merges the tiles with Chan's formula).  This lane's column over its rows,
+            // then over the four k-groups that hold the other rows of the tile.
             s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            const int cnt = min(tile_px, HWo - oy0 * a.Wo);                  // valid pixels of this tile (wave-uniform)
+            const float mt = s1 / (float)cnt;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = vals[i][r] - mt; if (ok[i][r]) m2 += d * d; }
+            m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
             if (kq == 0 && colok) {   // every (sample, tile, column) has exactly one writer: no atomics, run-to-run identical
                 float* cs = a.chsum + (((size_t)n * tiles_per_img + tile) * a.Cout + col) * 2;
-                cs[0] = s1; cs[1] = s2;
+                cs[0] = s1; cs[1] = m2;
             }
         }
     }
@@ -432,34 +444,47 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
     tconv_epilogue<NMT, NCT>(a, acc, n, tile, tiles_per_img, oy0, col0, kq);
 }
 
-// GroupNorm statistics of concat(A, B) from the producers' per-tile channel sums: stats[n][g] = (mean, rstd) with the single-pass
-// variance E[x^2] - mean^2 (fp32; activations are O(1)).  grid = NB, 256 work-items.
+// GroupNorm statistics of concat(A, B) from the producers' per-tile channel records (sum, squared deviations about the tile's own
+// mean): stats[n][g] = (mean, rstd).  The group's mean comes from the sums; its M2 is Chan's parallel merge
+// M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ] -- no E[x^2] - mean^2 cancellation, so a group whose mean is large against its
+// spread (trained checkpoints) keeps its variance (round-2 advisor finding).  pxA / pxB: pixels per full tile of each producer (the
+// last tile of an image may hold fewer).  grid = NB, 256 work-items.
 __global__ __launch_bounds__(RDMI_THREADS) void gn_finalize_kernel(const float* __restrict__ csA, const float* __restrict__ csB, int CA, int CB, int tilesA, int tilesB,
-                                                                    int HW, int G, float eps, float* __restrict__ stats) {
+                                                                    int pxA, int pxB, int HW, int G, float eps, float* __restrict__ stats) {
     // eight lanes per group (G <= 32): lane `sub` adds the (channel, tile) pairs sub, sub + 8, ... in a fixed order, then the eight
     // partial sums are merged by xor-shuffles -- the same order on every run
     const int n = blockIdx.x, g = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const int C = CA + CB, Cg = C / G;
-    float s1 = 0.f, s2 = 0.f;
+    const int tmax = max(tilesA, tilesB);
+    float s1 = 0.f;
     if (g < G) {
-        const int tmax = max(tilesA, tilesB);
         for (int e = sub; e < Cg * tmax; e += 8) {
             const int cc = e / tmax, t = e - cc * tmax, c = g * Cg + cc;
             const bool inA = c < CA;
             const int tiles = inA ? tilesA : tilesB;
+            if (t < tiles) s1 += ((inA ? csA : csB) + (((size_t)n * tiles + t) * (inA ? CA : CB) + (inA ? c : c - CA)) * 2)[0];
+        }
+    }
+    for (int m = 1; m < 8; m <<= 1) s1 += __shfl_xor(s1, m);
+    const float cnt = (float)(Cg * HW);
+    const float mean = s1 / cnt;
+    float m2 = 0.f;
+    if (g < G) {
+        for (int e = sub; e < Cg * tmax; e += 8) {
+            const int cc = e / tmax, t = e - cc * tmax, c = g * Cg + cc;
+            const bool inA = c < CA;
+            const int tiles = inA ? tilesA : tilesB, px = inA ? pxA : pxB;
             if (t < tiles) {
                 const float* p = (inA ? csA : csB) + (((size_t)n * tiles + t) * (inA ? CA : CB) + (inA ? c : c - CA)) * 2;
-                s1 += p[0]; s2 += p[1];
+                const float nt = (float)min(px, HW - t * px), d = p[0] / nt - mean;
+                m2 += p[1] + nt * d * d;
             }
         }
     }
-    for (int m = 1; m < 8; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+    for (int m = 1; m < 8; m <<= 1) m2 += __shfl_xor(m2, m);
     if (g < G && sub == 0) {
-        const float cnt = (float)(Cg * HW);
-        const float mean = s1 / cnt;
-        const float var = fmaxf(s2 / cnt - mean * mean, 0.f);
         stats[((size_t)n * G + g) * 2] = mean;
-        stats[((size_t)n * G + g) * 2 + 1] = 1.0f / sqrtf(var + eps);
+        stats[((size_t)n * G + g) * 2 + 1] = 1.0f / sqrtf(m2 / cnt + eps);
     }
 }
 

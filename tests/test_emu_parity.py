@@ -632,3 +632,43 @@ def test_tiled_plan_small_rgb_model(emu, dtype, tol):
     assert info.startswith('tiled'), info
     for n in range(2):
         assert float((s[n] - ref[n]).abs().max()) <= tol * float(ref[n].abs().max()), (n, dtype)
+
+
+def test_tiled_plan_groupnorm_statistics_with_large_group_means(emu):
+    """Round-2 advisor finding: GroupNorm statistics formed from the producing convs' per-tile channel records must survive groups
+    whose mean is large against their spread (trained checkpoints; the synthetic weights above have near-zero means).  Every conv bias
+    of the small RGB model is shifted by +40 (conv outputs have unit-order spread: |mean| / std ~ 40, so E[x^2] - mean^2 in fp32 would
+    lose ~3 digits of the variance), and the tiled plan (per-tile sums + squared deviations about the tile mean, merged with Chan's
+    formula) is compared with the torch oracle (F.group_norm) and with the exact two-pass statistics path (RDMI_TILED_STATS_PASS=1)."""
+    import __graft_entry__ as ge
+    from oracle import rd_oracle_torch as OT
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    sde = sde_lib.RVESDE(0.01, 50, N=1000)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 16, 16, generator=g); lab = torch.zeros(2, 1); t = torch.tensor([0.6, 0.3])
+
+    def run(envvars):
+        os.environ.update(envvars)
+        try:
+            model, params = _small_rgb_model(ge, 'f32')
+            sd = model.state_dict()
+            shifted = {}
+            for k, v in sd.items():
+                if k.endswith('Conv_0.bias') or k.endswith('Conv_1.bias') or k == 'input_conv.bias':
+                    shifted[k] = v + 40.0
+            model.load_state_dict({**sd, **shifted})
+            with torch.no_grad():
+                s = mutils.get_score_fn(sde, model)(x, t, class_labels=lab)
+            return s, {k: v.clone() for k, v in model.state_dict().items()}
+        finally:
+            for k in envvars:
+                os.environ.pop(k, None)
+    s, pt = run({})
+    s2, _ = run({'RDMI_TILED_STATS_PASS': '1'})
+    with torch.no_grad():
+        ref = OT.ncsnpp_forward(pt, x, OT.sigma_of(t, smax=50.0), lab, ch_mult=(1, 2, 2), nrb=1, attn_levels=(False, True, False), scale_by_sigma=True)
+    for n in range(2):
+        amp = float(ref[n].abs().max())
+        assert float((s[n] - ref[n]).abs().max()) <= 1e-4 * amp, (n, float((s[n] - ref[n]).abs().max()) / amp)
+        assert float((s[n] - s2[n]).abs().max()) <= 1e-4 * amp, n
