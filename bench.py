@@ -138,9 +138,28 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert x.shape[0] == B * world and bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
     ctx0 = model._ctx[(str(dev), args.height, args.width)]
-    assert not ctx0.coop_gave_up(), 'a co-operative launch gave up an inter-workgroup wait (its samples are NaN): see DESIGN 4.2d'
+    coop_fallback = ctx0.coop_gave_up()
+    if world > 1:                                  # every rank takes the same branch (the re-run below holds collectives)
+        flag = torch.tensor([1.0 if coop_fallback else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        coop_fallback = bool(flag.item() > 0)
+    if coop_fallback:
+        # A co-operative launch gave up an inter-workgroup wait (the groups were not co-resident: a shared or partitioned device):
+        # its samples are NaN and the context has switched to the single-sample program.  Time THAT, and say so.
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            x, nfe = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+    assert x.shape[0] == B * world and bool(torch.isfinite(x).all()) and float(x.min()) >= 0 and float(x.max()) <= 1
     # N > 1: how many ranks really took part (a sum of ones over the RCCL group) and what the one collective of the path costs alone
     ranks_seen, gather_us = 1, None
     if world > 1:
@@ -172,7 +191,7 @@ def main():
                    'global_batch': B * world, 'num_scales': args.num_scales, 'score_evals_per_traj': evals,
                    'parallelism': f'batch-sharded x{world}, one all-gather per sampling call' if world > 1 else 'single GPU'},
         'tflops_algorithmic': value * fwd_per_traj * GFLOP_PER_FORWARD / 1e3 / world,
-        'plan': ctx0.path_info(), 'ranks_seen': ranks_seen, 'all_gather_us': gather_us,
+        'plan': ctx0.path_info(), 'coop_fallback': coop_fallback, 'ranks_seen': ranks_seen, 'all_gather_us': gather_us,
     }
     if rank == 0 and not args.no_roofline:
         out['roofline'] = roofline(ge, model, cfg, sde, shape, labels, dev, args, value / world, fwd_per_traj)

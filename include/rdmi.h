@@ -238,7 +238,8 @@ int rdmi_debug_op_cycles(rdmi_ctx* ctx, long long* host_cycles, int cap, const c
 
 /* Diagnostic: has any co-operative launch of this context (groups of four workgroups sharing the low-resolution section of the
  * fused U-Net: DESIGN.md 4.2d) given up one of its bounded inter-workgroup waits?  *gave_up = 0: never; 1: yes -- the output
- * samples of the affected workgroups were overwritten with NaN by the kernel itself.  Synchronises the device. */
+ * samples of the affected workgroups were overwritten with NaN by the kernel itself; from then on the context stops selecting the
+ * co-operative program (its workgroups were evidently not resident together on this device).  Synchronises the device. */
 int rdmi_coop_status(rdmi_ctx* ctx, int* gave_up);
 
 /* Diagnostic: the N(0,1) draws the fused sampler makes when rdmi_pc_sample is called with noise == NULL

@@ -213,7 +213,7 @@ __device__ __forceinline__ u32x4 xbuf_load16(const XBuf& b, unsigned off) {
     return u32x4{q[0], q[1], q[2], q[3]};
 }
 __device__ __forceinline__ void spin_relax() { __builtin_amdgcn_s_sleep(1); }
-#define RDMI_SPIN_LIMIT (1ull << 21)
+#define RDMI_SPIN_LIMIT (1ull << 19)       // ~0.5 s of polling (a poll is a ~1 us round trip), then the workgroup gives up
 #elif defined(RDMI_EMU)
 struct XBuf { unsigned long long* p; };
 __device__ __forceinline__ XBuf xbuf_make(unsigned long long* p, unsigned) { return XBuf{p}; }

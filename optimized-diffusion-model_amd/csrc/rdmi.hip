@@ -1715,6 +1715,7 @@ int build_fused_program_pass(rdmi_ctx* c, int S, int TAB_RESERVE, int TAB1_RESER
         HIP_OK(hipMemset(c->cur_coop_err, 0, 16));
         c->fargs.coop = 1; c->fargs.coop_stride = c->coop_stride; c->fargs.xbuf = c->cur_xbuf; c->fargs.xslot = b.xslot_granules;
         c->fargs.coop_err = c->cur_coop_err;
+        if (const char* e = std::getenv("RDMI_COOP_TEST_BREAK")) c->fargs.coop_break = atoi(e);
         c->cur_coop = 1; c->cur_nxchg = b.n_xchg; c->cur_cap_n = coop_max_nb;
     }
     c->fused_lds = (size_t)b.high_water;
@@ -2157,6 +2158,7 @@ int rdmi_coop_status(rdmi_ctx* c, int* gave_up) {
     *gave_up = 0;
     for (auto& q : c->progs)
         if (q.coop && q.d_coop_err) { int v = 0; HIP_OK(hipMemcpy(&v, q.d_coop_err, sizeof v, hipMemcpyDeviceToHost)); *gave_up |= v; }
+    if (*gave_up) c->use_coop = false;       // the groups of this device were not co-resident once: later calls take the single-sample programs
     return 0;
 }
 const char* rdmi_version(void) {

@@ -137,6 +137,7 @@ struct UnetArgs {
     int out_elems;                                // floats per sample of the network output
     float drop_p; const unsigned long long* seed_dev;   // training forward: dropout probability and the step's seed (device word)
     int* coop_err;                                // set to 1 by a workgroup whose bounded wait gave up (its output sample is then NaN)
+    int coop_break;                               // test hook (RDMI_COOP_TEST_BREAK=1): member 3 of group 0 withholds its first publication, so the others' bounded wait must fire
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -973,10 +974,11 @@ __device__ __forceinline__ void fop_xchg(const OpW& w, const UnetArgs& u, int g,
     // NOTE (ROCm 7.2 clang): __builtin_bit_cast applied DIRECTLY to a vector element (bit_cast<T>(v[i])) reads element 0 whatever i is
     // -- copy the element into a scalar first.
     // ---- publish my block (mode 1: it comes from the single-sample tensor a_off and is also copied into my rows of the destination)
+    const bool withhold = u.coop_break != 0 && g == 0 && m == 3 && xi == 0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const int p = tid + k * UW_THREADS;
-        if (p < np) {
+        if (p < np && !withhold) {
             f32x2 v;
             if (mode == 0) v = *reinterpret_cast<const f32x2*>(lds_f(0) + at(p, m));
             else {
@@ -993,7 +995,11 @@ __device__ __forceinline__ void fop_xchg(const OpW& w, const UnetArgs& u, int g,
     const int nk = (np + UW_THREADS - 1) / UW_THREADS;          // passes over the pairs (wave-uniform)
     u32x4 y[3 * KMAX];
     unsigned long long spins = 0;
-    for (;;) {
+    // a give-up anywhere on the device (this launch or an earlier one: the word is never cleared) ends all waiting: the launches
+    // still queued finish at once instead of timing out exchange by exchange; their samples are marked like the first one's
+    bool broken = __hip_atomic_load(u.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (broken) *failw = 1;
+    for (; !broken;) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < nk) {
@@ -1009,13 +1015,13 @@ __device__ __forceinline__ void fop_xchg(const OpW& w, const UnetArgs& u, int g,
                 for (int jj = 0; jj < 3; ++jj) { const unsigned t1 = y[k * 3 + jj][1], t3 = y[k * 3 + jj][3]; ok &= t1 == epoch && t3 == epoch; }
             }
         if (ok) break;
-        if (++spins > RDMI_SPIN_LIMIT) { *failw = 1; *u.coop_err = 1; break; }
+        if (++spins > RDMI_SPIN_LIMIT) { *failw = 1; __hip_atomic_store(u.coop_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         spin_relax();
     }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const int p = tid + k * UW_THREADS;
-        if (k < nk && p < np) {
+        if (!broken && k < nk && p < np) {
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) {
                 const unsigned a = y[k * 3 + jj][0], b = y[k * 3 + jj][2];

@@ -97,6 +97,9 @@ inline f32x4_emu __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4_emu 
 }
 
 inline long long clock64() { return 0; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T> inline T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+template <class T, class V> inline void __hip_atomic_store(T* p, V v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_RELEASE); }
 inline float atomicAdd(float* p, float v) {   // workgroups run on parallel OS threads: a real atomic
     unsigned* u = reinterpret_cast<unsigned*>(p);
     unsigned old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
