@@ -85,9 +85,13 @@ __device__ __forceinline__ void wave_order_point() {}
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void opaque_sgpr(int& v) { asm volatile("" : "+s"(v)); }
+// "this value is first needed HERE": pins the use of a loaded value below the point of the call (the optimiser otherwise hoists
+// loop-invariant arithmetic on it -- and with it the s_waitcnt for the load -- above a long loop the load was meant to fly under)
+__device__ __forceinline__ void use_from_here(float& v) { asm volatile("" : "+v"(v)); }
 #else
 __device__ __forceinline__ void sched_fence() {}
 __device__ __forceinline__ void opaque_sgpr(int&) {}
+__device__ __forceinline__ void use_from_here(float&) {}
 #endif
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
@@ -212,6 +216,15 @@ __device__ __forceinline__ u32x4 xbuf_load16(const XBuf& b, unsigned off) {
     const xq_t q = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)off, 0, 16);
     return u32x4{q[0], q[1], q[2], q[3]};
 }
+// Weight stream of a conv main loop as a BUFFER load: wave-uniform base (resource in SGPRs) + a lane byte offset that never changes
+// + a wave-uniform byte offset advanced by scalar adds -- no vector ALU instruction per load (a global_load needs a 64-bit VALU add
+// for its address, and VALU instructions do not co-execute with fp32 MFMAs: scripts/micro/mfma_lds.hip, ~4 pipe cycles each).
+struct WBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ WBuf wbuf_make(const float* p) { return WBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, -1, 0x00020000)}; }
+__device__ __forceinline__ f32x4 wbuf_load4(const WBuf& b, unsigned lane_off, unsigned wave_off) {
+    const xq_t q = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)lane_off, (int)wave_off, 0);
+    return __builtin_bit_cast(f32x4, q);
+}
 __device__ __forceinline__ void spin_relax() { __builtin_amdgcn_s_sleep(1); }
 #define RDMI_SPIN_LIMIT (1ull << 19)       // ~0.5 s of polling (a poll is a ~1 us round trip), then the workgroup gives up
 #elif defined(RDMI_EMU)
@@ -225,6 +238,9 @@ __device__ __forceinline__ u32x4 xbuf_load16(const XBuf& b, unsigned off) {
     const unsigned long long a = __atomic_load_n(b.p + (off >> 3), __ATOMIC_ACQUIRE), c = __atomic_load_n(b.p + (off >> 3) + 1, __ATOMIC_ACQUIRE);
     return u32x4{(unsigned)a, (unsigned)(a >> 32), (unsigned)c, (unsigned)(c >> 32)};
 }
+struct WBuf { const char* p; };
+__device__ __forceinline__ WBuf wbuf_make(const float* p) { return WBuf{reinterpret_cast<const char*>(p)}; }
+__device__ __forceinline__ f32x4 wbuf_load4(const WBuf& b, unsigned lane_off, unsigned wave_off) { return *reinterpret_cast<const f32x4*>(b.p + lane_off + wave_off); }
 __device__ __forceinline__ void spin_relax() { emu::relax(); }
 #define RDMI_SPIN_LIMIT (1ull << 40)
 #else
@@ -232,6 +248,9 @@ struct XBuf { unsigned long long* p; };
 __device__ __forceinline__ XBuf xbuf_make(unsigned long long* p, unsigned) { return XBuf{p}; }
 __device__ __forceinline__ void xbuf_store16(const XBuf&, unsigned, unsigned, unsigned, unsigned) { abort(); }      // host pass of hipcc: never executed
 __device__ __forceinline__ u32x4 xbuf_load16(const XBuf&, unsigned) { abort(); return u32x4{0, 0, 0, 0}; }
+struct WBuf { const char* p; };
+__device__ __forceinline__ WBuf wbuf_make(const float* p) { return WBuf{reinterpret_cast<const char*>(p)}; }
+__device__ __forceinline__ f32x4 wbuf_load4(const WBuf& b, unsigned lane_off, unsigned wave_off) { return *reinterpret_cast<const f32x4*>(b.p + lane_off + wave_off); }
 __device__ __forceinline__ void spin_relax() {}
 #define RDMI_SPIN_LIMIT (1ull << 21)
 #endif

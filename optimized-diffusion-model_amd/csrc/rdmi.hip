@@ -2112,8 +2112,8 @@ int rdmi_debug_op_cycles(rdmi_ctx* c, long long* host, int cap, const char** des
     {
         std::vector<long long> fs((size_t)n * 8);
         if (hipMemcpy(fs.data(), c->d_stamps + 1024, fs.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int i = 0; i < n && 256 + i * 6 + 5 < cap; ++i)
-                for (int k = 0; k < 6; ++k) host[256 + i * 6 + k] = fs[(size_t)i * 8 + k] - st[(size_t)i];
+            for (int i = 0; i < n && 256 + i * 8 + 7 < cap; ++i)
+                for (int k = 0; k < 8; ++k) host[256 + i * 8 + k] = fs[(size_t)i * 8 + k] - st[(size_t)i];
     }
     for (int i = 0; i < n && i < desc_cap; ++i) desc[i] = q0.fdesc[(size_t)i].c_str();
     return n;

@@ -414,14 +414,20 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
 #pragma unroll
         for (int p = 0; p < PF; ++p) ring[p] = ldg4(Wl + (size_t)min(p, nsteps - 1) * bstride);
         int ph = 0, ch = KS ? kg : 0;
-        // row offsets of the current tap and, one tap AHEAD, of the next one: the table lookup (LDS read + address math)
-        // of a tap transition is issued a whole tap early, so the transition itself is a register move
-        int abase[NMT], anext[NMT];
+        // Row offsets of the current tap (abase), of the next one (anext) and -- still as the raw int16 table entry -- of the one after
+        // (araw).  A tap transition is then register moves plus address arithmetic on a table entry that was READ A WHOLE TAP AGO: the
+        // LDS read issued at the transition is not waited for until the next transition.  (With the lookup and its s_waitcnt inside the
+        // transition, every wave stalled for two dependent LDS round trips 8 times per 3x3 conv -- and the two waves of a SIMD reach
+        // their transitions together, so the matrix pipe idled: ~10 % of a 9x9 conv's main phase.)
+        static_assert(offsetof(FOp, tab_off) / 4 + 9 <= 64, "tap tables must sit in the first descriptor register");
+        auto tab_at = [&](int t) { return reinterpret_cast<const short*>(rdmi_lds + __builtin_amdgcn_readlane(w.w0, tab_word + t)); };
+        auto row_addr = [&](int r) { return (r < 0 ? zero_off : m_lds + r * m_rs * 4) + kq * 16; };
+        int abase[NMT], anext[NMT], araw[NMT];
 #pragma unroll
         for (int i = 0; i < NMT; ++i) {
-            abase[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
-            anext[i] = o_ntap > 1 ? arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word + 1)), mrow[i], m_lds, m_rs, zero_off) + kq * 16
-                                  : zero_off + kq * 16;
+            abase[i] = row_addr(tab_at(0)[mrow[i]]);
+            anext[i] = o_ntap > 1 ? row_addr(tab_at(1)[mrow[i]]) : zero_off + kq * 16;
+            araw[i] = o_ntap > 2 ? (int)tab_at(2)[mrow[i]] : -1;
         }
         f32x4 afn[NMT];
 #pragma unroll
@@ -440,18 +446,19 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
                 if (wrap) {
                     ++ph;
 #pragma unroll
-                    for (int i = 0; i < NMT; ++i) abase[i] = anext[i];
-                    if (ph + 1 < o_ntap) {
+                    for (int i = 0; i < NMT; ++i) {
+                        abase[i] = anext[i];
+                        anext[i] = ph + 1 < o_ntap ? row_addr(araw[i]) : zero_off + kq * 16;     // past the last tap: padding steps contribute 0
+                    }
+                    if (ph + 2 < o_ntap) {
 #pragma unroll
-                        for (int i = 0; i < NMT; ++i)
-                            anext[i] = arow(reinterpret_cast<const short*>(rdmi_lds + opw_at(w, tab_word + ph + 1)), mrow[i], m_lds, m_rs, zero_off) + kq * 16;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NMT; ++i) anext[i] = zero_off + kq * 16;     // padding steps contribute 0
+                        for (int i = 0; i < NMT; ++i) araw[i] = tab_at(ph + 2)[mrow[i]];
                     }
                 }
+                if (!(DIAG && (u.dbg & 2048))) {     // (ablation bit: no A-fragment reads in the loop)
 #pragma unroll
-                for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+                    for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + abase[i] + ch * 64);
+                }
                 RDMI_SCHED_FENCE();   // keep those LDS reads ABOVE this step's MFMAs (the scheduler otherwise sinks them below
                                       // and the next step starts with a full lgkmcnt(0) wait on a just-issued read)
                 if (M4) {           // <= 4 rows: the 4x4x1 multi-block form wastes no rows (13 vs 32 cycles per MFMA, see mfma4)
@@ -467,7 +474,7 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
                         for (int i = 0; i < NMT; ++i)
                             acc[i] = (LM4 && i == NMT - 1) ? mfma4(af[i][j], ring[p][j], acc[i]) : mfma16(af[i][j], ring[p][j], acc[i]);
                 }
-                ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nsteps - 1) * bstride);
+                if (!(DIAG && (u.dbg & 1024))) ring[p] = ldg4(Wl + (size_t)min(q + p + PF, nsteps - 1) * bstride);     // (ablation bit: no weight reloads)
             }
         }
     }
@@ -485,12 +492,123 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
     if (DIAG && fine) fine[4] = clock64();
 }
 
+// Main loop, TAP-MAJOR form, for ops whose 16-channel chunk count per tap is a multiple of 4 (every conv of the model but the
+// first, which contracts 16 channels).  Same arithmetic, same order of accumulation and the same operands as fconv_main; what differs
+// is the control code around the MFMAs.  fconv_main decides per step whether the tap changes (two branches, a 64-bit multiply for the
+// weight address, a clamp): ~20 scalar instructions and two taken branches between the last MFMA of a step and the first of the
+// next.  scripts/micro/mfma_lds.hip shows what that costs: two waves per SIMD running 12 MFMA + 3 ds_read_b128 + 1 global_load per
+// step keep the matrix pipe 89 % busy when the steps follow each other directly and 77-82 % with that inter-step section -- the
+// section of one wave does not hide under the other wave's MFMAs.  Here four steps (one turn of the weight ring) are straight-line
+// code; a tap can only end at a group boundary, where the next A addresses are a select between "next chunk" and "next tap"; the
+// weight address is a wave-uniform byte offset advanced by a scalar add + min.
+template <bool DIAG, int NMT, bool LM4 = false>
+__device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, int mt0, int WM, int nt, int lane, long long* fine, f32x4 (&acc)[4]) {
+    const int lrow = lane & 15, kq = lane >> 4;
+    if (DIAG && fine) fine[0] = clock64();
+    const int o_Cout_pad = OPI(w, Cout_pad), o_ntap = OPI(w, ntap);
+    const int m_lds = OPI(w, main_ph.lds_off), m_rs = OPI(w, main_ph.rs), nch = OPI(w, main_ph.nch);
+    const WBuf wb = wbuf_make(OPP(w, const float, main_ph.w));
+    const int tab_word = (int)(offsetof(FOp, tab_off) / 4);
+    const int zero_off = u.zero_off;
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int mrow[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + ((LM4 && i == NMT - 1) ? 0 : lrow);
+    // LM4: the last row tile holds ONE real row (81 = 5 x 16 + 1).  It is not worth a matrix instruction at all: every lane reads that
+    // row's A fragment (an LDS broadcast) and multiplies it with the weight fragment it already holds for the full tiles -- four VALU
+    // fma per step into element 0 of the tile's accumulator (the k-ordered fma chain an MFMA would run, per k quarter), summed over
+    // the four k quarters after the loop.  The 4x4x1 MFMA form used before cost 13 of the matrix pipe's cycles per instruction, 17 %
+    // of the pipe time of the wave that owns the tile, for one row in eighty-one.
+    const int nsteps = o_ntap * nch;
+    const unsigned bstride = (unsigned)o_Cout_pad * 64u;                       // bytes per step
+    const unsigned wend = (unsigned)(nsteps - 1) * bstride;
+    const unsigned lane_w = (unsigned)((nt * 16 + lrow) * 16 + kq * 4) * 4u;   // this lane's bytes inside a step's block
+    f32x4 ring[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ring[p] = wbuf_load4(wb, lane_w, min((unsigned)p * bstride, wend));
+    unsigned woff = min(4u * bstride, wend);                                   // byte offset of the next fragment to request
+    static_assert(offsetof(FOp, tab_off) / 4 + 9 <= 64, "tap tables must sit in the first descriptor register");
+    auto tab_at = [&](int t) { return reinterpret_cast<const short*>(rdmi_lds + __builtin_amdgcn_readlane(w.w0, tab_word + t)); };
+    auto row_addr = [&](int r) { return (r < 0 ? zero_off : m_lds + r * m_rs * 4) + kq * 16; };
+    int acur[NMT], anext[NMT], araw[NMT];      // A byte addresses of the current chunk group, of the next tap, raw table entry of the tap after
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) {
+        acur[i] = row_addr(tab_at(0)[mrow[i]]);
+        anext[i] = o_ntap > 1 ? row_addr(tab_at(1)[mrow[i]]) : zero_off + kq * 16;
+        araw[i] = o_ntap > 2 ? (int)tab_at(2)[mrow[i]] : -1;
+    }
+    f32x4 afn[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i]);
+    if (DIAG && fine) fine[1] = clock64();
+    const int gpt = nch >> 2;                  // groups of 4 steps per tap
+    int gl = gpt, t = 0;
+    const int ngroups = (DIAG && (u.dbg & 512)) ? 0 : o_ntap * gpt;
+    for (int g = 0; g < ngroups; ++g) {
+        const bool last = --gl == 0;           // this group ends its tap
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x4 af[NMT];
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) af[i] = afn[i];
+            // the next step's A fragment of tile i: next chunk of this tap, or (last step of a group) the first chunk of whatever follows
+            auto read_next = [&](int i) {
+                if (p < 3) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i] + (p + 1) * 64);
+                else { acur[i] = last ? anext[i] : acur[i] + 256; afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i]); }
+            };
+            // The LDS reads are dealt out BETWEEN the MFMA groups and the weight request comes last: memory instructions issued in a
+            // cluster ahead of the MFMAs cost matrix-pipe time, interleaved ones hide (scripts/micro/mfma_lds.hip: 814 -> 790 cycles
+            // per step pair).  The fences pin that order against the machine scheduler.
+            if (NMT == 1) {
+                acc[0] = mfma16(af[0][0], ring[p][0], acc[0]); acc2 = mfma16(af[0][1], ring[p][1], acc2);
+                RDMI_SCHED_FENCE(); read_next(0); RDMI_SCHED_FENCE();
+                acc[0] = mfma16(af[0][2], ring[p][2], acc[0]); acc2 = mfma16(af[0][3], ring[p][3], acc2);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < NMT; ++i) {
+                        if (LM4 && i == NMT - 1) acc[i][0] = __builtin_fmaf(af[i][j], ring[p][j], acc[i][0]);
+                        else acc[i] = mfma16(af[i][j], ring[p][j], acc[i]);
+                    }
+                    RDMI_SCHED_FENCE();
+                    if (j < NMT) read_next(j);
+                    RDMI_SCHED_FENCE();
+                }
+            }
+            ring[p] = wbuf_load4(wb, lane_w, woff);
+            woff = min(woff + bstride, wend);
+        }
+        if (last) {                            // tap transition, branch-free: register work on a table entry read a whole tap ago + one LDS read issued
+            gl = gpt; ++t;                     // (araw is -1 = "zero row" once the taps run out: the clamped re-read of the last table is discarded)
+            const bool more = t + 2 < o_ntap;
+            const short* const tb = tab_at(min(t + 2, o_ntap - 1));
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) {
+                anext[i] = row_addr(araw[i]);
+                const int r = tb[mrow[i]];
+                araw[i] = more ? r : -1;
+            }
+        }
+    }
+    if (NMT == 1) acc[0] += acc2;
+    if (LM4) {                                 // every lane ends with D[row 80][col lrow] in element 0 (rows 81..83 do not exist: 0)
+        float v = acc[NMT - 1][0];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[NMT - 1][0] = v;
+    }
+    if (DIAG && fine) fine[4] = clock64();
+}
+
 // Shared CONV epilogue for one wave's nmt row tiles x one column tile.  Destinations each get their own (wave-uniform) branch
 // so LDS stores stay ds_write and global stores stay global_store (a merged pointer would degrade both to flat_store).
 // Returns true when the op carries a fused GroupNorm: acc[] then holds the finished raw outputs (bias, temb, residual, scale
 // applied), this wave's partial sums are parked in LDS, and the caller runs fconv_gn_apply after a workgroup barrier.
 template <bool MS, bool TR = false>
-__device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n0, int mt0, int WM, int nt, int nmt, int lane, float add, const float (&dadd)[4],
+__device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n0, int mt0, int WM, int nt, int nmt, int lane, float add, float dadd0, const float (&daddm)[4],
                                           f32x4 (&acc)[4], float (&ps1)[4], float (&ps2)[4]) {
     const int lrow = lane & 15, kq = lane >> 4;
     const int o_rows = OPI(w, rows), o_Cout = OPI(w, Cout);
@@ -547,6 +665,9 @@ __device__ __forceinline__ bool fconv_epi(const OpW& w, const UnetArgs& u, int n
     const bool write_raw = gn_off < 0 || OPI(w, gn_raw) != 0;
     float* const g_dst = OPP(w, float, g_out) ? OPP(w, float, g_out) : u.out;
     const int OPI_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
+    float dadd[4];              // Dense_0 row: one value per op for a single-sample op, one per row tile for a multi-sample op
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dadd[i] = (MS && OPI_samp < 0) ? daddm[i] : dadd0;
     if (col < o_Cout) {
         if (o_resid >= 0) {
             const float* resp = lds_f(o_resid);
@@ -796,42 +917,38 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
     if (OPI(w, dst_kind) == 3 && OPI(w, qkv1)) { fconv_qkv(w, u, wave, lane); return; }
     const bool fused_gn = OPI(w, dst_kind) == 0 && OPI(w, gn_off) >= 0;      // host guarantees: then every wave has at most one pass below
     const int o_samp = MS ? OPI(w, samp) : 0, hw_shift = MS ? OPI(w, hw_shift) : 0;
-    const float* dense_base = u.dense + (size_t)o_dense;
+    const float* dense_base = u.dense + (size_t)max(o_dense, 0);
     f32x4 acc[4];
     float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
-    float gmul = 1.f, gadd = 0.f;
+    // Epilogue operands (bias, bias of the folded shortcut, Dense_0 row, GroupNorm affine) are requested now so that their latency
+    // hides under the GEMM -- as UNCONDITIONAL loads from clamped addresses whose results are first touched after the main loop:
+    // a conditional load or an early `a += b` makes the compiler wait for the data right here, one exposed L2 round trip per conv.
+    const int wcol = min(wn * 16 + (lane & 15), o_Cout - 1);
+    float gmul = ldg1((fused_gn ? OPP(w, const float, gamma) : o_bias) + wcol), gadd = ldg1((fused_gn ? OPP(w, const float, beta) : o_bias) + wcol);
     int k_mt0 = 0, k_nt = 0, k_nmt = 0;
     for (int nt = wn; nt < ntiles; nt += WN) {
-        // epilogue operands are fetched now so their global latency hides under the GEMM
-        const int col = nt * 16 + (lane & 15);
-        float add = 0.f;
-        if (col < o_Cout) {
-            add = ldg1(o_bias + col);
-            if (o_bias2) add += ldg1(o_bias2 + col);
-            if (fused_gn) { gmul = ldg1(OPP(w, const float, gamma) + col); gadd = ldg1(OPP(w, const float, beta) + col); }
-        }
+        const int col = nt * 16 + (lane & 15), colc = min(col, o_Cout - 1);
+        float add1 = ldg1(o_bias + colc), add2 = ldg1((o_bias2 ? o_bias2 : o_bias) + colc);
         // this wave's row tiles wm, wm+WM, ... in groups of at most 4 (only NMT 1..4 are instantiated)
         for (int mt0 = wm; mt0 < mtiles; mt0 += 4 * WM) {
             const int left = (mtiles - mt0 + WM - 1) >> lWM;
             const int nmt = left >= 4 ? 4 : left;
             // Dense_0(SiLU(temb)) of the sample each row tile belongs to (this lane's rows kq*4..+3 of a tile are one sample)
-            float dadd[4] = {0.f, 0.f, 0.f, 0.f};
-            if (o_dense >= 0 && col < o_Cout) {
-                if (o_samp >= 0) {
-                    const float dv = ldg1(dense_base + (size_t)min(n0 + o_samp, u.NB - 1) * u.dense_stride + col);
-                    dadd[0] = dadd[1] = dadd[2] = dadd[3] = dv;
-                } else {
+            float daddm[4] = {0.f, 0.f, 0.f, 0.f};
+            float dv = ldg1(dense_base + (o_dense >= 0 ? (size_t)min(n0 + max(o_samp, 0), u.NB - 1) * u.dense_stride + colc : 0));
+            if (MS && o_dense >= 0 && o_samp < 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < nmt) {
-                            const int sl = ((mt0 + i * WM) * 16 + (lane >> 4) * 4) >> hw_shift;
-                            dadd[i] = ldg1(dense_base + (size_t)min(n0 + sl, u.NB - 1) * u.dense_stride + col);
-                        }
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (i < nmt) {
+                        const int sl = ((mt0 + i * WM) * 16 + (lane >> 4) * 4) >> hw_shift;
+                        daddm[i] = ldg1(dense_base + (size_t)min(n0 + sl, u.NB - 1) * u.dense_stride + colc);
+                    }
             }
+            const bool tapm = (OPI(w, main_ph.nch) & 3) == 0;        // tap-major main loop (fconv_main_t)
             switch (nmt) {
                 case 1:
                     if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_main<DIAG, 1, UW_PF_M4, true>(w, u, mt0, WM, nt, lane, fine, acc);
+                    else if (tapm) fconv_main_t<DIAG, 1>(w, u, mt0, WM, nt, lane, fine, acc);
                     else fconv_main<DIAG, 1, UW_PF_N1>(w, u, mt0, WM, nt, lane, fine, acc);
                     break;
                 case 2: fconv_main<DIAG, 2, 8>(w, u, mt0, WM, nt, lane, fine, acc); break;
@@ -839,22 +956,32 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
                     // 81 rows = 5 full tiles + 1 row: the wave that owns the nearly empty last tile runs it on the 4x4x1 form
                     // (13 instead of 32 MFMA cycles per step); it shares its SIMD with a wave of full tiles, so the pipe time saved is real
                     const int last_rows = OPI(w, rows) - (mt0 + 2 * WM) * 16;
-                    if (last_rows >= 1 && last_rows <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_main<DIAG, 3, 4, false, true>(w, u, mt0, WM, nt, lane, fine, acc);
+                    const bool lm4 = last_rows >= 1 && last_rows <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3;
+                    if (tapm) { if (lm4) fconv_main_t<DIAG, 3, true>(w, u, mt0, WM, nt, lane, fine, acc); else fconv_main_t<DIAG, 3>(w, u, mt0, WM, nt, lane, fine, acc); }
+                    else if (lm4) fconv_main<DIAG, 3, 4, false, true>(w, u, mt0, WM, nt, lane, fine, acc);
                     else fconv_main<DIAG, 3, 4>(w, u, mt0, WM, nt, lane, fine, acc);
                     break;
                 }
-                case 4: fconv_main<DIAG, 4, 4>(w, u, mt0, WM, nt, lane, fine, acc); break;
+                case 4:
+                    if (tapm) fconv_main_t<DIAG, 4>(w, u, mt0, WM, nt, lane, fine, acc);
+                    else fconv_main<DIAG, 4, 4>(w, u, mt0, WM, nt, lane, fine, acc);
+                    break;
                 default: break;
             }
             if (DIAG && (u.dbg & 256)) continue;                 // ablation: no epilogue
-            fconv_epi<MS, TR>(w, u, n0, mt0, WM, nt, nmt, lane, add, dadd, acc, ps1, ps2);
+            use_from_here(add1); use_from_here(add2); use_from_here(dv);
+            const float add = col < o_Cout ? (o_bias2 ? add1 + add2 : add1) : 0.f, dadd0 = o_dense >= 0 ? dv : 0.f;
+            fconv_epi<MS, TR>(w, u, n0, mt0, WM, nt, nmt, lane, add, dadd0, daddm, acc, ps1, ps2);
             k_mt0 = mt0; k_nt = nt; k_nmt = nmt;
             if (DIAG && fine) fine[5] = clock64();
         }
     }
     if (fused_gn) {
+        use_from_here(gmul); use_from_here(gadd);
         lds_barrier();
+        if (DIAG && fine) fine[6] = clock64();
         if (k_nmt > 0) fconv_gn_apply<MS, TR>(w, u, n0, k_mt0, WM, k_nt, k_nmt, lane, gmul, gadd, acc, ps1, ps2);
+        if (DIAG && fine) fine[7] = clock64();
     }
 }
 
@@ -883,14 +1010,10 @@ __device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, i
     const float* o_bias = OPP(w, const float, bias); const float* o_bias2 = OPP(w, const float, bias2);
     const bool fused_gn = OPI(w, gn_off) >= 0;
     const bool finisher = kg == 0;
-    float add = 0.f, gmul = 1.f, gadd = 0.f;
-    float dadd[4] = {0.f, 0.f, 0.f, 0.f};
-    if (finisher && col < o_Cout) {                            // epilogue operands: their latency hides under the main loop
-        add = ldg1(o_bias + col);
-        if (o_bias2) add += ldg1(o_bias2 + col);
-        if (fused_gn) { gmul = ldg1(OPP(w, const float, gamma) + col); gadd = ldg1(OPP(w, const float, beta) + col); }
-        if (o_dense >= 0) dadd[0] = ldg1(u.dense + (size_t)o_dense + (size_t)min(n_grp + ((kq * 4) >> hw_shift), u.NB - 1) * u.dense_stride + col);
-    }
+    // epilogue operands: unconditional loads, first touched after the main loop (see fop_conv); every column is real (Cout = 128)
+    float add1 = ldg1(o_bias + col), add2 = ldg1((o_bias2 ? o_bias2 : o_bias) + col);
+    float gmul = ldg1((fused_gn ? OPP(w, const float, gamma) : o_bias) + col), gadd = ldg1((fused_gn ? OPP(w, const float, beta) : o_bias) + col);
+    float dv = ldg1(u.dense + (size_t)max(o_dense, 0) + (o_dense >= 0 ? (size_t)min(n_grp + ((kq * 4) >> hw_shift), u.NB - 1) * u.dense_stride + col : 0));
     f32x4 acc[4];
     fconv_main<DIAG, 1, UW_PF_KS1, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
     // park the partial this wave does not finish: K group kg goes to foreign column block (m + kg) & 3
@@ -901,6 +1024,7 @@ __device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r * drs] = acc[0][r];
     }
+    use_from_here(add1); use_from_here(add2); use_from_here(dv); use_from_here(gmul); use_from_here(gadd);
     lds_barrier();
     if (finisher) {
         f32x4 part[3];
@@ -915,7 +1039,7 @@ __device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, i
         // instruction cache): every row is real (16 rows = 4 samples x 4 pixels), every column is real (Cout = 128); this lane's four
         // rows kq*4 .. +3 ARE sample kq, so a GroupNorm group's statistic (4 channels x 4 pixels) is one quad reduction in registers
         const int o_resid = OPI(w, resid_off), o_resid_rs = OPI(w, resid_rs);
-        const float o_scale = OPF(w, scale), add_all = add + dadd[0];
+        const float o_scale = OPF(w, scale), add_all = (o_bias2 ? add1 + add2 : add1) + (o_dense >= 0 ? dv : 0.f);
         const int row0 = kq * 4;
         if (o_resid >= 0) {
             const float* rp = lds_f(o_resid) + (size_t)row0 * o_resid_rs + col;
@@ -1170,7 +1294,7 @@ __global__ __launch_bounds__(UW_THREADS) void unet_wg_kernel(UnetArgs u) {
     gn_prefetch(cur, tid, pgm, pbt);
     for (int pc = 0; pc < u.nops; ++pc) {
         const OpW nn = opw_load(u.prog + (pc + 2 < u.nops ? pc + 2 : u.nops - 1), lane);
-        long long* fine = (DIAG && u.stamps && n == 0 && tid == 0) ? u.stamps + 1024 + pc * 8 : nullptr;
+        long long* fine = (DIAG && u.stamps && n == 0 && tid == ((u.dbg >> 16) & 7) * 64) ? u.stamps + 1024 + pc * 8 : nullptr;   // RDMI_UDBG bits 16-18: the wave whose fine stamps are kept
         const int kind = OPI(cur, kind);
         if (DIAG && fine) fine[2] = clock64();
         f32x4 ngm = pgm, nbt = pbt;

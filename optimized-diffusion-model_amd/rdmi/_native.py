@@ -260,7 +260,7 @@ class Context:
         cyc = (C.c_longlong * 2048)()
         desc = (C.c_char_p * 512)()
         n = lib().rdmi_debug_op_cycles(self._h, cyc, 2048, desc, 512)
-        self.fine = [[int(cyc[256 + i * 6 + k]) for k in range(6)] for i in range(min(n, 250))]
+        self.fine = [[int(cyc[256 + i * 8 + k]) for k in range(8)] for i in range(min(n, 220))]
         return [(desc[i].decode(), int(cyc[i])) for i in range(n)]
 
     def path_info(self):

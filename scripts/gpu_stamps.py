@@ -4,6 +4,8 @@ os.environ['RDMI_STAMPS'] = '1'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'optimized-diffusion-model_amd'))
 import torch
+from rdmi import _native
+if os.environ.get('RDMI_VARIANT_LIB'): _native.use_library(os.environ['RDMI_VARIANT_LIB'])     # experimental build (scripts/build_variant.sh)
 import __graft_entry__ as ge
 from rdmi import sde_lib
 from rdmi.models import utils as mutils
@@ -24,7 +26,7 @@ ops = ctx.op_cycles()
 tot = sum(c for _, c in ops)
 agg = {}
 for i, (d, c) in enumerate(ops):
-    if not QUIET: print(f'{i:3d} {c:8d} {100*c/tot:5.1f}%  {d}' + (f'   fine(entry,ring,kind,prefetch,main,epi)={ctx.fine[i]}' if d.startswith('CONV') and i < len(ctx.fine) else ''))
+    if not QUIET: print(f'{i:3d} {c:8d} {100*c/tot:5.1f}%  {d}' + (f'   fine(entry,ring,kind,prefetch,main,epi,gnbar,gnapply)={ctx.fine[i]}' if d.startswith('CONV') and i < len(ctx.fine) else ''))
     k = d.split()[0] + (' ' + d.split()[1] if d.startswith('CONV') else '')
     agg[k] = agg.get(k, 0) + c
 print('total cycles', tot, ' (100 MHz ticks?)')
