@@ -501,7 +501,9 @@ __device__ __forceinline__ void fconv_main(const OpW& w, const UnetArgs& u, int 
 // section of one wave does not hide under the other wave's MFMAs.  Here four steps (one turn of the weight ring) are straight-line
 // code; a tap can only end at a group boundary, where the next A addresses are a select between "next chunk" and "next tap"; the
 // weight address is a wave-uniform byte offset advanced by a scalar add + min.
-template <bool DIAG, int NMT, bool LM4 = false>
+// PF: steps per straight-line group = depth of the weight ring (4, or 8 where a wave has a single row tile: its steps are only four
+// MFMAs long, so four steps of lookahead are ~1 k cycles -- no more than an L2 round trip under load); the chunk count per tap must be a multiple of PF.
+template <bool DIAG, int NMT, bool LM4 = false, int PF = 4, bool M4 = false>
 __device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, int mt0, int WM, int nt, int lane, long long* fine, f32x4 (&acc)[4]) {
     const int lrow = lane & 15, kq = lane >> 4;
     if (DIAG && fine) fine[0] = clock64();
@@ -515,7 +517,7 @@ __device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, in
     for (int i = 0; i < NMT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int mrow[NMT];
 #pragma unroll
-    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + ((LM4 && i == NMT - 1) ? 0 : lrow);
+    for (int i = 0; i < NMT; ++i) mrow[i] = (mt0 + i * WM) * 16 + ((LM4 && i == NMT - 1) ? 0 : M4 ? (lane & 3) : lrow);     // M4: an image of <= 4 pixels (4x4x1 MFMA form, see mfma4)
     // LM4: the last row tile holds ONE real row (81 = 5 x 16 + 1).  It is not worth a matrix instruction at all: every lane reads that
     // row's A fragment (an LDS broadcast) and multiplies it with the weight fragment it already holds for the full tiles -- four VALU
     // fma per step into element 0 of the tile's accumulator (the k-ordered fma chain an MFMA would run, per k quarter), summed over
@@ -525,10 +527,10 @@ __device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, in
     const unsigned bstride = (unsigned)o_Cout_pad * 64u;                       // bytes per step
     const unsigned wend = (unsigned)(nsteps - 1) * bstride;
     const unsigned lane_w = (unsigned)((nt * 16 + lrow) * 16 + kq * 4) * 4u;   // this lane's bytes inside a step's block
-    f32x4 ring[4];
+    f32x4 ring[PF];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) ring[p] = wbuf_load4(wb, lane_w, min((unsigned)p * bstride, wend));
-    unsigned woff = min(4u * bstride, wend);                                   // byte offset of the next fragment to request
+    for (int p = 0; p < PF; ++p) ring[p] = wbuf_load4(wb, lane_w, min((unsigned)p * bstride, wend));
+    unsigned woff = min((unsigned)PF * bstride, wend);                                   // byte offset of the next fragment to request
     static_assert(offsetof(FOp, tab_off) / 4 + 9 <= 64, "tap tables must sit in the first descriptor register");
     auto tab_at = [&](int t) { return reinterpret_cast<const short*>(rdmi_lds + __builtin_amdgcn_readlane(w.w0, tab_word + t)); };
     auto row_addr = [&](int r) { return (r < 0 ? zero_off : m_lds + r * m_rs * 4) + kq * 16; };
@@ -543,25 +545,29 @@ __device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, in
 #pragma unroll
     for (int i = 0; i < NMT; ++i) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i]);
     if (DIAG && fine) fine[1] = clock64();
-    const int gpt = nch >> 2;                  // groups of 4 steps per tap
+    const int gpt = nch / PF;                  // groups of PF steps per tap
     int gl = gpt, t = 0;
     const int ngroups = (DIAG && (u.dbg & 512)) ? 0 : o_ntap * gpt;
     for (int g = 0; g < ngroups; ++g) {
         const bool last = --gl == 0;           // this group ends its tap
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PF; ++p) {
             f32x4 af[NMT];
 #pragma unroll
             for (int i = 0; i < NMT; ++i) af[i] = afn[i];
             // the next step's A fragment of tile i: next chunk of this tap, or (last step of a group) the first chunk of whatever follows
             auto read_next = [&](int i) {
-                if (p < 3) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i] + (p + 1) * 64);
-                else { acur[i] = last ? anext[i] : acur[i] + 256; afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i]); }
+                if (p < PF - 1) afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i] + (p + 1) * 64);
+                else { acur[i] = last ? anext[i] : acur[i] + PF * 64; afn[i] = *reinterpret_cast<const f32x4*>(rdmi_lds + acur[i]); }
             };
             // The LDS reads are dealt out BETWEEN the MFMA groups and the weight request comes last: memory instructions issued in a
             // cluster ahead of the MFMAs cost matrix-pipe time, interleaved ones hide (scripts/micro/mfma_lds.hip: 814 -> 790 cycles
             // per step pair).  The fences pin that order against the machine scheduler.
-            if (NMT == 1) {
+            if (M4) {
+                acc[0] = mfma4(af[0][0], ring[p][0], acc[0]); acc2 = mfma4(af[0][1], ring[p][1], acc2);
+                RDMI_SCHED_FENCE(); read_next(0); RDMI_SCHED_FENCE();
+                acc[0] = mfma4(af[0][2], ring[p][2], acc[0]); acc2 = mfma4(af[0][3], ring[p][3], acc2);
+            } else if (NMT == 1) {
                 acc[0] = mfma16(af[0][0], ring[p][0], acc[0]); acc2 = mfma16(af[0][1], ring[p][1], acc2);
                 RDMI_SCHED_FENCE(); read_next(0); RDMI_SCHED_FENCE();
                 acc[0] = mfma16(af[0][2], ring[p][2], acc[0]); acc2 = mfma16(af[0][3], ring[p][3], acc2);
@@ -594,12 +600,87 @@ __device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, in
         }
     }
     if (NMT == 1) acc[0] += acc2;
+    if (M4) {                                  // sum the four k quarters: every lane then holds D[row r][col lrow] (see fconv_main)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[0][r];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[0][r] = v;
+        }
+    }
     if (LM4) {                                 // every lane ends with D[row 80][col lrow] in element 0 (rows 81..83 do not exist: 0)
         float v = acc[NMT - 1][0];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         acc[NMT - 1][0] = v;
     }
+    if (DIAG && fine) fine[4] = clock64();
+}
+
+// Tap-major main loop of the CO-OPERATIVE convs (one row tile, K dealt to four wave groups: wave group kg takes 16-channel chunks
+// kg, kg + 4, ... of every tap -- SPT = nch / 4 steps per tap, 2 at 128 input channels, 4 at 256).  A straight-line group is four
+// steps = 4 / SPT taps; taps beyond the last one (9 taps in groups of two) read the zero row and a clamped weight block: exact zeros.
+// acc[0] is this wave's PARTIAL sum (fop_conv_coop adds the four).
+template <bool DIAG, int SPT>
+__device__ __forceinline__ void fconv_main_ks(const OpW& w, const UnetArgs& u, int nt, int lane, long long* fine, f32x4 (&acc)[4], int kg) {
+    constexpr int TPG = 4 / SPT;               // taps per group
+    const int lrow = lane & 15, kq = lane >> 4;
+    if (DIAG && fine) fine[0] = clock64();
+    const int o_Cout_pad = OPI(w, Cout_pad), o_ntap = OPI(w, ntap);
+    const int m_lds = OPI(w, main_ph.lds_off), m_rs = OPI(w, main_ph.rs);
+    const WBuf wb = wbuf_make(OPP(w, const float, main_ph.w));
+    const int tab_word = (int)(offsetof(FOp, tab_off) / 4);
+    const int zero_off = u.zero_off;
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = o_ntap * SPT;
+    const unsigned bstride = (unsigned)o_Cout_pad * 256u;                      // bytes between this wave's steps (4 chunks)
+    const unsigned w0 = (unsigned)kg * o_Cout_pad * 64u, wend = w0 + (unsigned)(nsteps - 1) * bstride;
+    const unsigned lane_w = (unsigned)((nt * 16 + lrow) * 16 + kq * 4) * 4u;
+    f32x4 ring[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ring[p] = wbuf_load4(wb, lane_w, min(w0 + (unsigned)p * bstride, wend));
+    unsigned woff = min(w0 + 4u * bstride, wend);
+    auto tab_at = [&](int t) { return reinterpret_cast<const short*>(rdmi_lds + __builtin_amdgcn_readlane(w.w0, tab_word + t)); };
+    auto row_addr = [&](int r) { return (r < 0 ? zero_off : m_lds + r * m_rs * 4) + kg * 64 + kq * 16; };      // (the zero row is as long as the widest tensor row)
+    int a[TPG], an[TPG], araw[TPG];            // this group's taps, the next group's, raw table entries of the group after
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) {
+        a[k] = k < o_ntap ? row_addr(tab_at(k)[lrow]) : row_addr(-1);
+        an[k] = TPG + k < o_ntap ? row_addr(tab_at(TPG + k)[lrow]) : row_addr(-1);
+        araw[k] = 2 * TPG + k < o_ntap ? (int)tab_at(2 * TPG + k)[lrow] : -1;
+    }
+    f32x4 afn = *reinterpret_cast<const f32x4*>(rdmi_lds + a[0]);
+    if (DIAG && fine) fine[1] = clock64();
+    const int ngroups = (DIAG && (u.dbg & 512)) ? 0 : (o_ntap + TPG - 1) / TPG;
+    for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x4 af = afn;
+            acc[0] = mfma16(af[0], ring[p][0], acc[0]); acc2 = mfma16(af[1], ring[p][1], acc2);
+            RDMI_SCHED_FENCE();
+            if (p < 3) afn = *reinterpret_cast<const f32x4*>(rdmi_lds + a[(p + 1) / SPT] + ((p + 1) % SPT) * 256);
+            else {
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) a[k] = an[k];
+                afn = *reinterpret_cast<const f32x4*>(rdmi_lds + a[0]);
+            }
+            RDMI_SCHED_FENCE();
+            acc[0] = mfma16(af[2], ring[p][2], acc[0]); acc2 = mfma16(af[3], ring[p][3], acc2);
+            ring[p] = wbuf_load4(wb, lane_w, woff);
+            woff = min(woff + bstride, wend);
+        }
+        // group transition, branch-free: addresses from table entries read a group ago, one LDS read per tap issued
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            const int t = (g + 3) * TPG + k;
+            an[k] = row_addr(araw[k]);
+            const int r = tab_at(min(t, o_ntap - 1))[lrow];
+            araw[k] = t < o_ntap ? r : -1;
+        }
+    }
+    acc[0] += acc2;
     if (DIAG && fine) fine[4] = clock64();
 }
 
@@ -945,9 +1026,13 @@ __device__ __forceinline__ void fop_conv(const OpW& w, const UnetArgs& u, int n0
                     }
             }
             const bool tapm = (OPI(w, main_ph.nch) & 3) == 0;        // tap-major main loop (fconv_main_t)
+            const bool tapm8 = (OPI(w, main_ph.nch) & 7) == 0;
             switch (nmt) {
                 case 1:
-                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) fconv_main<DIAG, 1, UW_PF_M4, true>(w, u, mt0, WM, nt, lane, fine, acc);
+                    if (OPI(w, rows) <= 4 && OPI(w, dst_kind) != 1 && OPI(w, dst_kind) != 3) {
+                        if (tapm8) fconv_main_t<DIAG, 1, false, 8, true>(w, u, mt0, WM, nt, lane, fine, acc);
+                        else fconv_main<DIAG, 1, UW_PF_M4, true>(w, u, mt0, WM, nt, lane, fine, acc);
+                    } else if (tapm8) fconv_main_t<DIAG, 1, false, 8>(w, u, mt0, WM, nt, lane, fine, acc);
                     else if (tapm) fconv_main_t<DIAG, 1>(w, u, mt0, WM, nt, lane, fine, acc);
                     else fconv_main<DIAG, 1, UW_PF_N1>(w, u, mt0, WM, nt, lane, fine, acc);
                     break;
@@ -1015,7 +1100,12 @@ __device__ __forceinline__ void fop_conv_coop(const OpW& w, const UnetArgs& u, i
     float gmul = ldg1((fused_gn ? OPP(w, const float, gamma) : o_bias) + col), gadd = ldg1((fused_gn ? OPP(w, const float, beta) : o_bias) + col);
     float dv = ldg1(u.dense + (size_t)max(o_dense, 0) + (o_dense >= 0 ? (size_t)min(n_grp + ((kq * 4) >> hw_shift), u.NB - 1) * u.dense_stride + col : 0));
     f32x4 acc[4];
-    fconv_main<DIAG, 1, UW_PF_KS1, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
+    {
+        const int spt = OPI(w, main_ph.nch) >> 2;           // steps per tap of a wave group
+        if (spt == 2) fconv_main_ks<DIAG, 2>(w, u, nt, lane, fine, acc, kg);
+        else if (spt == 4 && (OPI(w, main_ph.nch) & 3) == 0) fconv_main_ks<DIAG, 4>(w, u, nt, lane, fine, acc, kg);
+        else fconv_main<DIAG, 1, UW_PF_KS1, false, false, true>(w, u, 0, 1, nt, lane, fine, acc, kg);
+    }
     // park the partial this wave does not finish: K group kg goes to foreign column block (m + kg) & 3
     float* const dstp = lds_f(OPI(w, dst_off));
     const int drs = OPI(w, dst_rs);
