@@ -93,6 +93,12 @@ __device__ __forceinline__ void sched_fence() {}
 __device__ __forceinline__ void opaque_sgpr(int&) {}
 __device__ __forceinline__ void use_from_here(float&) {}
 #endif
+// a * b + c on the full-rate 24-bit integer multiplier (operands < 2^24): v_mad_u32_u24 instead of the quarter-rate v_mul_lo_u32
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int mad_u24(int a, int b, int c) { return (int)(__umul24((unsigned)a, (unsigned)b) + (unsigned)c); }
+#else
+__device__ __forceinline__ int mad_u24(int a, int b, int c) { return a * b + c; }
+#endif
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 // Activation tensors of the training step are fp32 or (train_dtype = bf16) bf16 in HBM: same element indexing, `bf` selects the

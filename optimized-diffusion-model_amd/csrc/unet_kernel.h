@@ -533,12 +533,13 @@ __device__ __forceinline__ void fconv_main_t(const OpW& w, const UnetArgs& u, in
     unsigned woff = min((unsigned)PF * bstride, wend);                                   // byte offset of the next fragment to request
     static_assert(offsetof(FOp, tab_off) / 4 + 9 <= 64, "tap tables must sit in the first descriptor register");
     auto tab_at = [&](int t) { return reinterpret_cast<const short*>(rdmi_lds + __builtin_amdgcn_readlane(w.w0, tab_word + t)); };
-    auto row_addr = [&](int r) { return (r < 0 ? zero_off : m_lds + r * m_rs * 4) + kq * 16; };
+    const int rs4 = m_rs * 4, lds_kq = m_lds + kq * 16, zero_kq = zero_off + kq * 16;
+    auto row_addr = [&](int r) { return r < 0 ? zero_kq : mad_u24(r, rs4, lds_kq); };      // (row index and row bytes are far below 2^24)
     int acur[NMT], anext[NMT], araw[NMT];      // A byte addresses of the current chunk group, of the next tap, raw table entry of the tap after
 #pragma unroll
     for (int i = 0; i < NMT; ++i) {
         acur[i] = row_addr(tab_at(0)[mrow[i]]);
-        anext[i] = o_ntap > 1 ? row_addr(tab_at(1)[mrow[i]]) : zero_off + kq * 16;
+        anext[i] = o_ntap > 1 ? row_addr(tab_at(1)[mrow[i]]) : zero_kq;
         araw[i] = o_ntap > 2 ? (int)tab_at(2)[mrow[i]] : -1;
     }
     f32x4 afn[NMT];
@@ -643,7 +644,8 @@ __device__ __forceinline__ void fconv_main_ks(const OpW& w, const UnetArgs& u, i
     for (int p = 0; p < 4; ++p) ring[p] = wbuf_load4(wb, lane_w, min(w0 + (unsigned)p * bstride, wend));
     unsigned woff = min(w0 + 4u * bstride, wend);
     auto tab_at = [&](int t) { return reinterpret_cast<const short*>(rdmi_lds + __builtin_amdgcn_readlane(w.w0, tab_word + t)); };
-    auto row_addr = [&](int r) { return (r < 0 ? zero_off : m_lds + r * m_rs * 4) + kg * 64 + kq * 16; };      // (the zero row is as long as the widest tensor row)
+    const int rs4 = m_rs * 4, lds_kq = m_lds + kg * 64 + kq * 16, zero_kq = zero_off + kg * 64 + kq * 16;      // (the zero row is as long as the widest tensor row)
+    auto row_addr = [&](int r) { return r < 0 ? zero_kq : mad_u24(r, rs4, lds_kq); };
     int a[TPG], an[TPG], araw[TPG];            // this group's taps, the next group's, raw table entries of the group after
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
