@@ -17,7 +17,9 @@ struct PackJob {
     int n_off;                // first destination column of this job
     int ntap;
     long s_co, s_ci, s_t;     // source strides (elements) of output channel, input channel, tap
-    int kind;                 // 0: pack weights, 1: plain copy of Cout floats to dst + n_off, 2: pack weights as bf16 [tap][K/32][Npad][32]
+    int kind;                 // 0: pack weights, 1: plain copy of Cout floats to dst + n_off, 2: pack weights as bf16 [tap][K/32][Npad][32],
+                              // 3: pack the PRODUCT src (W [Cin][Cout], NIN layout) x src2 (W [Cout][Cout]), 4: the vector src (Cout floats) x src2 -> dst + n_off
+    const float* src2;        // kinds 3 / 4: the right-hand factor (a NIN weight [in][out])
 };
 
 __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __restrict__ jobs) {
@@ -25,6 +27,14 @@ __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __res
     const int stride = gridDim.x * RDMI_THREADS;
     if (j.kind == 1) {
         for (int i = blockIdx.x * RDMI_THREADS + threadIdx.x; i < j.Cout; i += stride) j.dst[j.n_off + i] = j.src[i];
+        return;
+    }
+    if (j.kind == 4) {        // row vector x matrix: the bias of a projection folded into the next one (rdmi.hip: attention value path)
+        for (int i = blockIdx.x * RDMI_THREADS + threadIdx.x; i < j.Cout; i += stride) {
+            float acc = 0.f;
+            for (int k = 0; k < j.Cin; ++k) acc = fmaf(j.src[k], j.src2[(long)k * j.Cout + i], acc);
+            j.dst[j.n_off + i] = acc;
+        }
         return;
     }
     if (j.kind == 2) {        // bf16 copy of the weights for v_mfma_f32_16x16x32_bf16: 32 consecutive k per (k-slab, column)
@@ -55,7 +65,11 @@ __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __res
         const int t = (int)(r / (j.Kpad >> 4));
         const int ci = ch * 16 + kk;
         float v = 0.f;
-        if (co < j.Cout && ci < j.Cin) v = j.src[co * j.s_co + ci * j.s_ci + t * j.s_t];
+        if (co < j.Cout && ci < j.Cin) {
+            if (j.kind == 3) {                            // (W W2)[ci][co]; the middle dimension is W's output = W2's input = Cout channels
+                for (int k = 0; k < j.Cout; ++k) v = fmaf(j.src[(long)ci * j.s_ci + k * j.s_co], j.src2[(long)k * j.Cout + co], v);
+            } else v = j.src[co * j.s_co + ci * j.s_ci + t * j.s_t];
+        }
         j.dst[(((long)t * (j.Kpad >> 4) + ch) * j.Npad + j.n_off + co) * 16 + kk] = v;
     }
 }

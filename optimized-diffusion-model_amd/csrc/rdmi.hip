@@ -125,6 +125,7 @@ struct rdmi_ctx {
     std::vector<Op> ops;
     std::vector<PackJob> jobs;          // host copy (src pointers patched from params before upload)
     std::vector<int> job_param;         // param index feeding each job
+    std::vector<int> job_param2;        // second source of a job (PackJob::src2), -1: none; filled up to jobs.size() in do_repack
     PackJob* d_jobs = nullptr;
     float* d_w = nullptr;               // packed weight arena
     size_t w_floats = 0;
@@ -482,6 +483,30 @@ struct Builder {
                 c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
             }
             c->wmap[name + ".qkv3"] = o3;
+        }
+        {   // the same block with NIN_3 folded into the value projection: softmax(QK^T) (V W3) == (softmax(QK^T) V) W3, so the inference
+            // programs of the workgroup-resident kernel run no NIN_3 op at all (fused_attn); v-columns = NIN_2.W x NIN_3.W, v-bias = NIN_2.b x NIN_3.W
+            const size_t o3 = alloc_w((size_t)3 * C * C);
+            for (int i = 0; i < 3; ++i) {
+                PackJob j{};
+                j.dst = reinterpret_cast<float*>(o3);
+                j.Cin = C; j.Cout = C; j.Kpad = C; j.Npad = 3 * C; j.n_off = i * C; j.ntap = 1; j.s_co = 1; j.s_ci = C; j.s_t = 0; j.kind = i == 2 ? 3 : 0;
+                c->jobs.push_back(j);
+                c->job_param.push_back(c->pindex.at(name + ".NIN_" + std::to_string(i) + ".W"));
+                c->job_param2.resize(c->jobs.size(), -1);
+                if (i == 2) c->job_param2.back() = c->pindex.at(name + ".NIN_3.W");
+            }
+            c->wmap[name + ".qkv3f"] = o3;
+            const size_t ob = alloc_w((size_t)3 * C);
+            c->wmap[name + ".bqkvf"] = ob;
+            for (int i = 0; i < 2; ++i) job_copy(name + ".NIN_" + std::to_string(i) + ".b", ob, C, i * C);
+            PackJob j{};
+            j.dst = reinterpret_cast<float*>(ob);
+            j.Cin = C; j.Cout = C; j.n_off = 2 * C; j.kind = 4;
+            c->jobs.push_back(j);
+            c->job_param.push_back(c->pindex.at(name + ".NIN_2.b"));
+            c->job_param2.resize(c->jobs.size(), -1);
+            c->job_param2.back() = c->pindex.at(name + ".NIN_3.W");
         }
         op.bqkv_off = alloc_w((size_t)3 * C);
         c->wmap[name + ".bqkv"] = op.bqkv_off;
@@ -1365,10 +1390,14 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
     const int ps = Lpad + 4;
     const int vt_bytes = C * ps * 4, p_bytes = L * ps * 4;
     const int vt_off = b.alloc_top(vt_bytes);
-    const size_t bq = c->wmap.at(name + ".bqkv");
+    // Inference programs fold NIN_3 into the value projection (weights packed as ".qkv3f" / ".bqkvf"): the attention op then writes
+    // (P V' + b3 + x) / sqrt2 itself and the 1x1 NIN_3 conv -- 10-15 k cycles of almost pure per-op overhead, five times per forward --
+    // disappears.  The training forward keeps the reference's op sequence (the backward needs the tensor between P V and NIN_3).
+    const bool fold3 = !b.train && std::getenv("RDMI_NO_ATTN_FOLD") == nullptr;
+    const size_t bq = c->wmap.at(name + (fold3 ? ".bqkvf" : ".bqkv"));
     {   // q, k, v in one contraction: the layer plan already packs NIN_0..2 side by side? no: [3][C/16][C][16] -> use the
         // dedicated fused packing [C/16][3C][16] (wmap key ".qkv3")
-        const int idx = b.conv(xn, H, W, H, W, 1, 0, 1, name + ".qkv3", 0, 3 * C, "", bq, 3, &q, 1.f, -1, nullptr, nullptr, "", "");
+        const int idx = b.conv(xn, H, W, H, W, 1, 0, 1, name + (fold3 ? ".qkv3f" : ".qkv3"), 0, 3 * C, "", bq, 3, &q, 1.f, -1, nullptr, nullptr, "", "");
         FOp& o = c->fprog[(size_t)idx];
         o.dst2_off = k.off; o.dst3_off = vt_off; o.dst3_rs = ps; o.split_C = C;
         o.qkv1 = (std::getenv("RDMI_NO_QKV1") == nullptr && o.ntap == 1 && o.main_ph.nch == 4 && o.Cout_pad == 192 && C == 64 && o.mtiles <= 6) ? 1 : 0;
@@ -1381,10 +1410,13 @@ FusedBuilder::LT fused_attn(FusedBuilder& b, const std::string& name, FusedBuild
         a.q_off = q.off; a.k_off = k.off; a.qk_rs = q.rs; a.vt_off = vt_off; a.p_off = p_off; a.ps = ps;
         a.L = L; a.Lpad = Lpad; a.C = C; a.att_scale = 1.0f / std::sqrt((float)C);
         a.dst_off = o.off; a.dst_rs = o.rs;
-        b.emit(a);
+        if (fold3) { a.resid_off = x.off; a.resid_rs = x.rs; a.scale = (float)(1.0 / std::sqrt(2.0)); }
+        const int ia = b.emit(a);
+        if (fold3) b.patch_param(ia, FusedBuilder::F_BIAS, name + ".NIN_3.b");
     }
     b.tfree(q); b.tfree(k);
     b.free_bytes(vt_off, vt_bytes); b.free_bytes(p_off, p_bytes);
+    if (fold3) { b.tfree(x); return o; }
     LT out = b.talloc(C, H, W);
     b.conv(o, H, W, H, W, 1, 0, 1, name + ".NIN_3", 0, C, name + ".NIN_3.b", 0, 0, &out, (float)(1.0 / std::sqrt(2.0)), -1, &x, nullptr, "", "");
     b.tfree(o);
@@ -1828,6 +1860,9 @@ int do_repack(rdmi_ctx* c, hipStream_t s) {
         const Param& p = c->params[(size_t)c->job_param[i]];
         if (!p.ptr) return fail("parameter '%s' was never bound (rdmi_set_param)", p.name.c_str());
         c->jobs[i].src = p.ptr;
+        const int p2 = i < c->job_param2.size() ? c->job_param2[i] : -1;
+        c->jobs[i].src2 = p2 >= 0 ? c->params[(size_t)p2].ptr : nullptr;
+        if (p2 >= 0 && !c->jobs[i].src2) return fail("parameter '%s' was never bound (rdmi_set_param)", c->params[(size_t)p2].name.c_str());
     }
     for (auto& p : c->params)
         if (!p.ptr) return fail("parameter '%s' was never bound (rdmi_set_param)", p.name.c_str());

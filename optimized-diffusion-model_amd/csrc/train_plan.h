@@ -391,7 +391,11 @@ unsigned long long param_ptr_hash(const rdmi_ctx* c);
 int train_refresh_params(rdmi_ctx* c, TrainPlan& T, hipStream_t s) {
     for (auto& p : c->params)
         if (!p.ptr) return fail("parameter '%s' was never bound (rdmi_set_param)", p.name.c_str());
-    for (size_t i = 0; i < c->jobs.size(); ++i) c->jobs[i].src = c->params[(size_t)c->job_param[i]].ptr;
+    for (size_t i = 0; i < c->jobs.size(); ++i) {
+        c->jobs[i].src = c->params[(size_t)c->job_param[i]].ptr;
+        const int p2 = i < c->job_param2.size() ? c->job_param2[i] : -1;
+        c->jobs[i].src2 = p2 >= 0 ? c->params[(size_t)p2].ptr : nullptr;
+    }
     for (size_t i = 0; i < T.jobs.size(); ++i) T.jobs[i].src = c->params[(size_t)T.job_param[i]].ptr;
     auto same = [](const std::vector<PackJob>& a, const std::vector<PackJob>& b) { return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(PackJob)) == 0); };
     if (!same(T.m_jobs_fwd, c->jobs)) {

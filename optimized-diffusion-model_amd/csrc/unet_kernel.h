@@ -1327,13 +1327,21 @@ __device__ __forceinline__ void fop_attn(const OpW& w, int wave, int lane) {
             }
         }
         float* O = lds_f(o.dst_off);
+        // with NIN_3 folded into the value projection (rdmi.hip: fused_attn) this IS the block's output: (P V' + b3 + x) / sqrt2
+        const float* b3 = OPP(w, const float, bias);
+        const int o_resid = OPI(w, resid_off), o_resid_rs = OPI(w, resid_rs);
+        const float o_scale = OPF(w, scale), badd = b3 ? ldg1(b3 + col) : 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int mt = wm + 2 * i;
             if (mt < mtiles)
                 for (int r = 0; r < 4; ++r) {
                     const int row = mt * 16 + kq * 4 + r;
-                    if (row < L) O[(size_t)row * o.dst_rs + col] = acc[i][r];
+                    if (row < L) {
+                        float v = acc[i][r];
+                        if (b3) v = (v + badd + lds_f(o_resid)[(size_t)row * o_resid_rs + col]) * o_scale;
+                        O[(size_t)row * o.dst_rs + col] = v;
+                    }
                 }
         }
     }
