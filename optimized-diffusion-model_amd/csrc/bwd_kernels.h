@@ -21,33 +21,32 @@
 // kernels consume), the identity-residual branch gR += G, and the per-sample column sums of G [HW][C]:
 // gdense[n][off + c] = sum_p G[n][p][c] (Dense_0 path, optional) and the bias gradients db[c] (+ db2[c]) += sum (atomics).
 // 256 work-items = (256 / cw) row lanes x cw columns per pass, partial sums merged in LDS.
-__global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const float* __restrict__ gY, float* __restrict__ G,
-                                                                         float* __restrict__ gR, float scale, float* __restrict__ gdense,
-                                                                         int dense_stride, int dense_off, float* __restrict__ db,
-                                                                         float* __restrict__ db2, int HW, int C, int g_bf16) {
-    __shared__ float red[RDMI_THREADS];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    for (int c0 = 0; c0 < C; c0 += RDMI_THREADS) {
-        const int cw = min(RDMI_THREADS, C - c0), R = RDMI_THREADS / cw;
+struct ColsumArgs {
+    const float* gY; float* G; float* gR; float scale; float* gdense; int dense_stride, dense_off; float* db; float* db2; int HW, C, g_bf16;
+};
+template <int NT>
+__device__ __forceinline__ void bwd_scale_colsum_body(const ColsumArgs& a, int n, int tid, float* red) {      // red: NT floats of LDS
+    for (int c0 = 0; c0 < a.C; c0 += NT) {
+        const int cw = min(NT, a.C - c0), R = NT / cw;
         const int r = tid / cw, c = c0 + tid - r * cw;
         float s = 0.f;
         if (r < R)
-            for (int p0 = r; p0 < HW; p0 += 4 * R) {            // four pixels per pass: their loads are issued before any store
+            for (int p0 = r; p0 < a.HW; p0 += 4 * R) {            // four pixels per pass: their loads are issued before any store
                 float gy[4], gr[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p = p0 + u * R;
-                    const size_t i = ((size_t)n * HW + min(p, HW - 1)) * C + c;
-                    gy[u] = gY[i]; gr[u] = gR ? gR[i] : 0.f;
+                    const size_t i = ((size_t)n * a.HW + min(p, a.HW - 1)) * a.C + c;
+                    gy[u] = a.gY[i]; gr[u] = a.gR ? a.gR[i] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p = p0 + u * R;
-                    if (p < HW) {
-                        const size_t i = ((size_t)n * HW + p) * C + c;
-                        const float g = gy[u] * scale;
-                        stact1(G, i, g, g_bf16);
-                        if (gR) gR[i] = gr[u] + g;
+                    if (p < a.HW) {
+                        const size_t i = ((size_t)n * a.HW + p) * a.C + c;
+                        const float g = gy[u] * a.scale;
+                        stact1(a.G, i, g, a.g_bf16);
+                        if (a.gR) a.gR[i] = gr[u] + g;
                         s += g;
                     }
                 }
@@ -57,12 +56,16 @@ __global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(const fl
         if (tid < cw) {
             float tot = 0.f;
             for (int j = 0; j < R; ++j) tot += red[tid + j * cw];
-            if (gdense) gdense[(size_t)n * dense_stride + dense_off + c] = tot;
-            if (db) atomicAdd(db + c, tot);
-            if (db2) atomicAdd(db2 + c, tot);
+            if (a.gdense) a.gdense[(size_t)n * a.dense_stride + a.dense_off + c] = tot;
+            if (a.db) atomicAdd(a.db + c, tot);
+            if (a.db2) atomicAdd(a.db2 + c, tot);
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(RDMI_THREADS) void bwd_scale_colsum_kernel(ColsumArgs a) {
+    __shared__ float red[RDMI_THREADS];
+    bwd_scale_colsum_body<RDMI_THREADS>(a, blockIdx.x, threadIdx.x, red);
 }
 
 // GroupNorm(+SiLU+dropout) backward for one sample per workgroup (GN_THREADS work-items), everything in LDS, followed by the
@@ -84,6 +87,10 @@ struct GnBwdArgs {
     const unsigned long long* seed_dev;   // non-null: dropout seed in device memory (see ConvArgs::seed_dev)
     int a_bf16, b_bf16, s_bf16;   // element type of srcA, of srcB, and of the scratch tensors GA / ACT (0 fp32, 1 bf16)
     float* gA; float* gB; const int* inv_start; const int* inv_list;   // fp32 gradient accumulators (null: that source takes no gradient)
+    // tail.G != null: this workgroup then runs the first backward kernel of the NEXT conv op (bwd_scale_colsum) for its sample -- the
+    // gradient that kernel reads is complete for sample n once this workgroup's scatter is (every earlier contribution is an earlier
+    // launch on the same stream).  One launch, and one ~6 us launch gap of the serial backward chain, less per conv op.
+    ColsumArgs tail;
 };
 __host__ __device__ inline size_t gn_bwd_lds_bytes(int HWv, int Cv) { return ((size_t)2 * (HWv + 1) * (Cv + 4) + 4 * 32 + 2 * GN_THREADS) * 4; }
 
@@ -215,6 +222,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(GnBwdArgs a) {
                 if (i < tot) { const int v = i / a.CB, c = i - v * a.CB; gb[i] = old[u] + Gt[(size_t)v * rs + a.CA + c]; }
             }
         }
+    }
+    if (a.tail.G) {
+        __syncthreads();                                         // this workgroup's scatter stores are complete and visible to all of its work-items
+        bwd_scale_colsum_body<GN_THREADS>(a.tail, n, tid, red);
     }
 }
 

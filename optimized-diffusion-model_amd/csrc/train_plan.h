@@ -34,6 +34,7 @@ struct TrainPlan {
     float *GA = nullptr, *GS = nullptr, *zero_bias = nullptr;
     hipStream_t side = nullptr; hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool two_streams = true;             // RDMI_TRAIN_STREAMS=1 keeps everything on the caller's stream
+    bool fuse_colsum = true;             // RDMI_TRAIN_FUSE_COLSUM=0: every conv op launches its own bwd_scale_colsum_kernel (diagnostic)
     float *gdense = nullptr, *gta = nullptr, *gh1 = nullptr, *four = nullptr, *sig_copy = nullptr, *lab_copy = nullptr;
     std::vector<size_t> poff;            // flat-gradient offset of every parameter
     size_t ptotal = 0;
@@ -292,6 +293,7 @@ int build_train_plan(rdmi_ctx* c, TrainPlan& T) {
     HIP_OK(hipMalloc((void**)&T.d_jobs, std::max<size_t>(T.jobs.size(), 1) * sizeof(PackJob)));
     for (auto& j : T.jobs) j.dst = T.d_wb + reinterpret_cast<size_t>(j.dst);
     if (const char* e = getenv("RDMI_TRAIN_STREAMS")) T.two_streams = atoi(e) != 1;
+    if (const char* e = getenv("RDMI_TRAIN_FUSE_COLSUM")) T.fuse_colsum = atoi(e) != 0;
     if (const char* e = getenv("RDMI_TRAIN_GROUP")) { T.group = std::max(1, std::min(TrainPlan::MAXSETS / 2, atoi(e))); T.group_env = true; }
     if (!T.two_streams) T.group = 1;
     for (int p = 0; p < 2 * T.group; ++p) {
@@ -570,6 +572,16 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         pending.clear();
         return 0;
     };
+    bool colsum_fused = false;                              // the current op's bwd_scale_colsum ran as the tail of the previous op's gn_bwd
+    auto colsum_args = [&](int oj, int pj) {
+        const Op& o2 = c->ops[(size_t)oj];
+        const BwdConv& b2 = *bmap.at(oj);
+        ColsumArgs ca{};
+        ca.gY = o2.out_is_output ? grad_out : gptr(o2.out_tensor); ca.G = T.G[pj]; ca.gR = gptr(o2.tRes); ca.scale = o2.conv.out_scale;
+        ca.gdense = o2.use_dense ? T.gdense : (float*)nullptr; ca.dense_stride = c->dense_total; ca.dense_off = o2.conv.dense_off;
+        ca.db = pgrad(b2.p_b); ca.db2 = pgrad(b2.p_bsc); ca.HW = o2.conv.HWo; ca.C = o2.spec.Cout; ca.g_bf16 = sbf;
+        return ca;
+    };
     for (int oi = (int)c->ops.size() - 1; oi >= 0; --oi) {
         const Op& op = c->ops[(size_t)oi];
         if (op.kind == OP_ATTN) {
@@ -594,10 +606,22 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
         const int p = nconv % (2 * grp), half = p / grp;
         ++nconv;
         float* Gp = T.G[p]; float* ACTp = T.ACT[p]; float* ACTSp = T.ACTS[p];
-        if (T.two_streams && p % grp == 0 && done_rec[half]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[half], 0));   // the group before last has left this half
-        // G = scale * gY (+ identity residual) and the bias / NIN-bias / Dense_0 gradients (column sums of G)
-        hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, gY, Gp, gptr(op.tRes), fa.out_scale,
-                           op.use_dense ? T.gdense : (float*)nullptr, c->dense_total, fa.dense_off, pgrad(b.p_b), pgrad(b.p_bsc), fa.HWo, sp.Cout, sbf);
+        if (T.two_streams && p % grp == 0 && done_rec[half] && !colsum_fused) HIP_OK(hipStreamWaitEvent(s, T.ev_done[half], 0));   // the group before last has left this half
+        // G = scale * gY (+ identity residual) and the bias / NIN-bias / Dense_0 gradients (column sums of G): its own launch only where the
+        // previous backward kernel was not a GroupNorm backward that could carry it as its tail (first op, ops behind an attention block)
+        if (!colsum_fused) {
+            const ColsumArgs ca = colsum_args(oi, p);
+            hipLaunchKernelGGL(bwd_scale_colsum_kernel, dim3((unsigned)NB), dim3(RDMI_THREADS), 0, s, ca);
+        }
+        colsum_fused = false;
+        // the next conv op's first kernel rides on this op's last GroupNorm backward
+        ColsumArgs tail{};
+        if (T.fuse_colsum && oi > 0 && c->ops[(size_t)oi - 1].kind != OP_ATTN) {
+            const int pn = nconv % (2 * grp), hn = pn / grp;           // (nconv already counts this op)
+            if (T.two_streams && pn % grp == 0 && done_rec[hn]) HIP_OK(hipStreamWaitEvent(s, T.ev_done[hn], 0));   // its buffer set must be free before the tail writes G
+            tail = colsum_args(oi - 1, pn);
+            colsum_fused = true;
+        }
         // data gradient w.r.t. the activated input
         if (b.has_dgrad) {
             ConvArgs d = b.dgrad; d.NB = NB; d.srcA = Gp;
@@ -618,6 +642,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             }
             const size_t lds = gn_bwd_lds_bytes(fa.HWv, fa.Cv);
             if (lds > 160 * 1024) return fail("gn backward of %s: LDS %zu B", sp.name.c_str(), lds);
+            if (!b.has_sc) g.tail = tail;
             hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(GN_THREADS), lds, s, g);
         }
         // NIN shortcut: data gradient and its scatter (ACTS = the shortcut's input, for its weight gradient)
@@ -630,6 +655,7 @@ int rdmi_backward(rdmi_ctx* c, const float* grad_out, float* grads_flat, size_t 
             g.GA = T.GS; g.ACT = ACTSp; g.has_gn = 0; g.a_bf16 = sbf; g.b_bf16 = sbf; g.s_bf16 = sbf;
             g.gA = gptr(op.tScA); g.gB = gptr(op.tScB);
             if (b.has_invS) { g.inv_start = T.d_int + b.invS_start; g.inv_list = T.d_int + b.invS_list; }
+            g.tail = tail;
             hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)NB), dim3(GN_THREADS), gn_bwd_lds_bytes(fa.HWo, fa.Csc), s, g);
         }
         // weight gradients on the side stream (reference OIHW layout): dW[co][ci][t] += sum ACT[in(o,t)][ci] G[o][co];  NIN: dWn += Vs^T G
