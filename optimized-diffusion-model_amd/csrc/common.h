@@ -93,6 +93,19 @@ __device__ __forceinline__ void sched_fence() {}
 __device__ __forceinline__ void opaque_sgpr(int&) {}
 __device__ __forceinline__ void use_from_here(float&) {}
 #endif
+// glds16: asynchronous 16-byte-per-lane copy global -> LDS without a register round trip (global_load_lds_dwordx4, the LDS-DMA of
+// gfx950).  The SOURCE address is per lane; the DESTINATION is wave-uniform: lane l's 16 bytes land at rdmi_lds + wave_off + 16 l
+// (M0 base + lane * size), so a swizzled LDS image is built by permuting the source addresses.  Completion is counted on vmcnt:
+// the __syncthreads() that precedes the first read of the image drains it (hipcc emits s_waitcnt vmcnt(0) before the barrier).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void glds16(const void* g, unsigned wave_off) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(rdmi_lds + wave_off), 16, 0, 0);
+}
+#elif defined(RDMI_EMU)
+__device__ __forceinline__ void glds16(const void* g, unsigned wave_off) { std::memcpy(rdmi_lds + wave_off + 16 * emu::lane_id(), g, 16); }
+#else
+__device__ __forceinline__ void glds16(const void*, unsigned) {}
+#endif
 // a * b + c on the full-rate 24-bit integer multiplier (operands < 2^24): v_mad_u32_u24 instead of the quarter-rate v_mul_lo_u32
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ int mad_u24(int a, int b, int c) { return (int)(__umul24((unsigned)a, (unsigned)b) + (unsigned)c); }

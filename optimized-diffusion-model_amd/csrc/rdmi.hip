@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -169,7 +170,8 @@ struct rdmi_ctx {
                                       // 6 GroupNorm(+SiLU) written once as bf16 for a pre-activated conv (bf16 plan), 7 fused softmax(QK^T)V (bf16 plan)
         std::string name;
         TConvArgs conv{}; int nmt = 4; bool pre = false;          // pre: input is the bf16 tensor a kind-6 launch wrote (tconv_pre_kernel)
-        GnActArgs gact{};                                                                                       // kind 6
+        size_t oOut2 = (size_t)-1;                                                                              // kind 6: second output (raw bf16 copy)
+        GnActArgs gact{}; bool fin = false; size_t oCsA = (size_t)-1, oCsB = (size_t)-1;                        // kind 6 (fin: statistics from the producers' channel records inside the launch)
         FlashArgs flash{}; int flashC = 0;                                                                      // kind 7: fused attention core (bf16 plan)
         const float *sA = nullptr, *sB = nullptr; int CA = 0, CB = 0, HW = 0, G = 0; float* stats = nullptr;     // kind 1
         BgemmArgs gemm{};                                                                                       // kind 2
@@ -189,6 +191,8 @@ struct rdmi_ctx {
     bf16_t* d_w16 = nullptr;             // bf16 copies of the forward conv weights (training with compute_dtype = bf16)
     std::vector<TLaunch> tl;
     float *t_ws = nullptr, *t_xin = nullptr, *t_out = nullptr; size_t t_ws_per_sample = 0;
+    long iconv_min_wgs = LONG_MAX;                      // iconv_kernel from this many 128 x 128 tiles per launch (off unless RDMI_ICONV=1 / RDMI_ICONV_MIN_WGS)
+    void* t_zero = nullptr;                             // 256 zero bytes: iconv_kernel's source for window pixels outside the image
     std::vector<FusedProg> progs;
     int s_min_wg = 256;                            // a program with S samples per workgroup is used from batch s_min_wg * S (RDMI_S_MIN_WG: tests)
     bool use_coop = true;                          // RDMI_COOP=0: never select the co-operative program (A/B, tests)
@@ -597,7 +601,8 @@ struct TiledBuilder {
     }
     // conv over concat(A, B) [optionally GroupNorm(+SiLU)'d with `st`], 3x3 (stride 1 pad 1 | stride 2 Downsample | nearest x2 Upsample) or 1x1
     TT conv(const std::string& name, const TT& A, const TT* B, const TT* st, const std::string& gn, bool act, int ntap, int stride, bool up,
-            size_t w_off, int cout, const std::string& bias_param, size_t bias_arena, int dense_off, const TT* resid, float scale, bool final_out) {
+            size_t w_off, int cout, const std::string& bias_param, size_t bias_arena, int dense_off, const TT* resid, float scale, bool final_out,
+            TT* raw_copy = nullptr) {     // raw_copy: if the conv takes the pre-activated form, its activation pass also leaves the RAW input as a bf16 [HW][Cv] tensor here
         // bf16 plan: a 3x3 stride-1 conv behind a GroupNorm reads a tensor that was normalised, activated and rounded to bf16 ONCE
         // (kind 6) instead of redoing that arithmetic for every staged window element (RDMI_NO_PREACT=1: the one-kernel form)
         // (3x3 stride-1 convs and the 1x1 q/k/v projection of attention blocks); a tensor that already is bf16 (the fused attention
@@ -613,9 +618,27 @@ struct TiledBuilder {
             act_off = actT.off;
             rdmi_ctx::TLaunch g; g.kind = 6; g.name = name + ".act";
             g.oA = A.off; g.oB = B ? B->off : rdmi_ctx::TLaunch::NONE; g.oStats = st->off; g.oOut = actT.off;
+            if (raw_copy && std::getenv("RDMI_NO_RAW_COPY") == nullptr) {
+                *raw_copy = talloc((Cvp + 1) / 2, A.H, A.W);
+                raw_copy->C = Cvp; raw_copy->bf = true;
+                g.oOut2 = raw_copy->off;
+            }
             g.gact.CA = A.C; g.gact.CB = B ? B->C : 0; g.gact.Cv = Cvp; g.gact.HW = A.H * A.W;
             g.gact.G = std::min(Cin / 4, 32); g.gact.Cg = Cin / g.gact.G; g.gact.act = act ? 1 : 0;
             g.p_gamma = gn + ".weight"; g.p_beta = gn + ".bias";
+            // the statistics launch of this GroupNorm (kind 5: from the producers' channel records) is folded into the activation pass:
+            // gn_act_fin_kernel reads the records itself (RDMI_NO_GN_FOLD=1 keeps the two launches)
+            int max_slots = 0;                                          // groups a 64-channel slice touches (the kernel's table holds 16)
+            for (int c_lo = 0; c_lo < Cin; c_lo += 64) max_slots = std::max(max_slots, (std::min(c_lo + 64, Cin) - 1) / g.gact.Cg - c_lo / g.gact.Cg + 1);
+            if (Cvp % 64 == 0 && max_slots <= 16 && g.gact.Cg <= 16 && std::getenv("RDMI_NO_GN_FOLD") == nullptr)
+                for (size_t k = c->tl.size(); k-- > 0 && k + 4 > c->tl.size();)
+                    if (c->tl[k].kind == 5 && c->tl[k].oStats == st->off) {
+                        const rdmi_ctx::TLaunch& f = c->tl[k];
+                        g.fin = true; g.oCsA = f.oA; g.oCsB = f.oB;
+                        g.gact.tilesA = f.tL; g.gact.tilesB = f.tC; g.gact.pxA = f.pxA; g.gact.pxB = f.pxB; g.gact.eps = 1e-6f;
+                        c->tl.erase(c->tl.begin() + (long)k);
+                        break;
+                    }
             c->tl.push_back(g);
         }
         TConvArgs a{};
@@ -654,13 +677,18 @@ struct TiledBuilder {
         const int cin = A.C + (B ? B->C : 0);
         const float rs2 = (float)(1.0 / std::sqrt(2.0));
         TT st0 = stats(name + ".GroupNorm_0", A, B);
+        // bf16 plan: GroupNorm_0's activation pass reads the block's raw input anyway and leaves a bf16 copy of it for the NIN_0
+        // shortcut, which then is a copy-staged 1x1 conv over half the bytes instead of a conv that converts fp32 while staging
+        TT xraw;
         TT h1 = conv(name + ".Conv_0", A, B, &st0, name + ".GroupNorm_0", true, 9, 1, false, pack3x3(name + ".Conv_0", cin, cout), cout,
-                     name + ".Conv_0.bias", (size_t)-1, dense_off, nullptr, 1.f, false);
+                     name + ".Conv_0.bias", (size_t)-1, dense_off, nullptr, 1.f, false, cin != cout ? &xraw : nullptr);
         TT st1 = stats(name + ".GroupNorm_1", h1, nullptr);
         const size_t w1 = pack3x3(name + ".Conv_1", cout, cout);
         if (cin != cout) {
-            TT sc = conv(name + ".NIN_0", A, B, nullptr, "", false, 1, 1, false, pack1x1(name + ".NIN_0", cin, cout), cout, name + ".NIN_0.b", (size_t)-1, -1,
-                         nullptr, 1.f, false);
+            TT sc = xraw.valid ? conv(name + ".NIN_0", xraw, nullptr, nullptr, "", false, 1, 1, false, pack1x1(name + ".NIN_0", cin, cout), cout, name + ".NIN_0.b", (size_t)-1, -1,
+                                      nullptr, 1.f, false)
+                               : conv(name + ".NIN_0", A, B, nullptr, "", false, 1, 1, false, pack1x1(name + ".NIN_0", cin, cout), cout, name + ".NIN_0.b", (size_t)-1, -1,
+                                      nullptr, 1.f, false);
             return conv(name + ".Conv_1", h1, nullptr, &st1, name + ".GroupNorm_1", true, 9, 1, false, w1, cout, name + ".Conv_1.bias", (size_t)-1, -1, &sc, rs2, false);
         }
         return conv(name + ".Conv_1", h1, nullptr, &st1, name + ".GroupNorm_1", true, 9, 1, false, w1, cout, name + ".Conv_1.bias", (size_t)-1, -1, &A, rs2, false);
@@ -782,6 +810,13 @@ int finish_tiled_plan(rdmi_ctx* c) {
     HIP_OK(hipMalloc((void**)&c->t_ws, c->t_ws_per_sample * NBmax * sizeof(float)));
     HIP_OK(hipMalloc((void**)&c->t_xin, E * NBmax * sizeof(float)));
     HIP_OK(hipMalloc((void**)&c->t_out, E * NBmax * sizeof(float)));
+    HIP_OK(hipMalloc(&c->t_zero, 256));
+    HIP_OK(hipMemset(c->t_zero, 0, 256));
+    // measured on MI355X (rocprofv3 kernel trace, B = 64 with guidance): 5.28 ms for the 3x3 convs of the 32x32 / 16x16 levels against 4.88 ms
+    // with tconv_pre_kernel -- the implicit-GEMM form is NOT the default; RDMI_ICONV=1 selects it (from RDMI_ICONV_MIN_WGS tiles, default 256)
+    c->iconv_min_wgs = LONG_MAX;
+    if (const char* e = std::getenv("RDMI_ICONV")) if (std::atoi(e) != 0) c->iconv_min_wgs = 256;
+    if (const char* e = std::getenv("RDMI_ICONV_MIN_WGS")) c->iconv_min_wgs = std::atol(e);
     for (auto& l : c->tl) {
         if (l.kind == 0) {
             TConvArgs& a = l.conv;
@@ -790,6 +825,7 @@ int finish_tiled_plan(rdmi_ctx* c) {
             a.wpk = c->d_w + l.w_off;
             a.dense = l.use_dense ? c->d_dense : nullptr;
             a.chsum = tl_ptr(c, l.oC);
+            a.zeros = c->t_zero;
             if (l.pre && tconv_trv(a) * tconv_wl(a) * (a.ntap == 1 ? TpCfg<1>::UPP : TpCfg<9>::UPP) > TC_MAXS * RDMI_THREADS)
                 return fail("tiled conv %s: window of %d pixels exceeds the register staging", l.name.c_str(), tconv_trv(a) * tconv_wl(a));
             if (l.pre && tconv_pre_lds_bytes(a) > 160 * 1024) return fail("tiled conv %s: LDS window %zu B", l.name.c_str(), tconv_pre_lds_bytes(a));
@@ -808,6 +844,8 @@ int finish_tiled_plan(rdmi_ctx* c) {
         } else if (l.kind == 6) {
             l.gact.A = tl_ptr(c, l.oA); l.gact.B = tl_ptr(c, l.oB); l.gact.stats = tl_ptr(c, l.oStats);
             l.gact.out = reinterpret_cast<bf16_t*>(tl_ptr(c, l.oOut));
+            l.gact.out2 = reinterpret_cast<bf16_t*>(tl_ptr(c, l.oOut2));
+            if (l.fin) { l.gact.csA = tl_ptr(c, l.oCsA); l.gact.csB = tl_ptr(c, l.oCsB); l.gact.stats = nullptr; }
         } else {
             l.tsrc = tl_ptr(c, l.oA); l.tdst = tl_ptr(c, l.oOut);
         }
@@ -2059,12 +2097,25 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             dim3 grid(tiles * (unsigned)NB, (unsigned)ceil_div(ca.Cout_pad, 64 * nct));
             const bool h = a.compute_dtype == 1;
             const size_t lds = l.pre ? tconv_pre_lds_bytes(ca) : h ? tconv_bf16_lds_bytes(ca) : tconv_lds_bytes(ca);
-            ProfScope ps(c, s, l.pre ? "tconv_pre_kernel<bf16>" : h ? "tconv_kernel<bf16>" : "tconv_kernel<fp32>", l.flops_per_sample * NB);
 #define RDMI_TCONV_PRE(NMT_, NCT_)                                                                                                    \
     do {                                                                                                                              \
         if (ca.ntap == 1) hipLaunchKernelGGL((tconv_pre_kernel<NMT_, NCT_, 1>), grid, dim3(RDMI_THREADS), lds, s, ca);                \
         else hipLaunchKernelGGL((tconv_pre_kernel<NMT_, NCT_, 9>), grid, dim3(RDMI_THREADS), lds, s, ca);                             \
     } while (0)
+            // implicit-GEMM form (iconv_kernel: 128 x 128 tiles over the whole batch's pixels) once the launch has a workgroup per CU
+            // (read at context creation -- off by default, see finish_tiled_plan; RDMI_ICONV_MIN_WGS: tests set the threshold to reach the kernel at fixture batches)
+            if (l.pre && ca.stride == 1 && !ca.up && ca.TR * ca.Wo == 64 && (ca.Ho * ca.Wo) % 64 == 0 && ca.Cout % 128 == 0 && ca.Cv % 64 == 0) {
+                const long M = (long)NB * ca.Ho * ca.Wo;
+                const dim3 g2((unsigned)((M + 127) / 128), (unsigned)(ca.Cout / 128));
+                if ((long)g2.x * g2.y >= c->iconv_min_wgs) {
+                    static const bool by_shape = std::getenv("RDMI_PROF_SHAPES") != nullptr;      // diagnostic: one profile row per conv shape
+                    ProfScope ps2(c, s, by_shape ? "iconv_kernel<bf16> " + std::to_string(ca.Wo) + "x" + std::to_string(ca.Ho) + " K" + std::to_string(ca.ntap * ca.Cv) + " N" + std::to_string(ca.Cout) + (ca.resid ? " +res" : "") : std::string("iconv_kernel<bf16>"), l.flops_per_sample * NB);
+                    if (ca.ntap == 1) hipLaunchKernelGGL((iconv_kernel<1>), g2, dim3(RDMI_THREADS), iconv_lds_bytes(), s, ca);
+                    else hipLaunchKernelGGL((iconv_kernel<9>), g2, dim3(RDMI_THREADS), iconv_lds_bytes(), s, ca);
+                    continue;
+                }
+            }
+            ProfScope ps(c, s, l.pre ? "tconv_pre_kernel<bf16>" : h ? "tconv_kernel<bf16>" : "tconv_kernel<fp32>", l.flops_per_sample * NB);
             if (l.pre) {
                 if (l.nmt == 4) { if (nct == 4) RDMI_TCONV_PRE(4, 4); else if (nct == 2) RDMI_TCONV_PRE(4, 2); else RDMI_TCONV_PRE(4, 1); }
                 else { if (nct == 4) RDMI_TCONV_PRE(1, 4); else if (nct == 2) RDMI_TCONV_PRE(1, 2); else RDMI_TCONV_PRE(1, 1); }
@@ -2101,6 +2152,11 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             else hipLaunchKernelGGL(flash_attn_bf16_kernel<64>, grid, dim3(RDMI_THREADS), flash_lds_bytes<64>(), s, fa);
         } else if (l.kind == 6) {
             GnActArgs g = l.gact; g.NB = NB;
+            if (l.fin) {
+                ProfScope ps(c, s, "gn_act_fin_kernel", 0);
+                hipLaunchKernelGGL(gn_act_fin_kernel, dim3((unsigned)ceil_div(g.HW, GA_PIX), (unsigned)(g.Cv / 64), (unsigned)NB), dim3(RDMI_THREADS), gn_act_fin_lds_bytes(std::max(g.tilesA, g.tilesB)), s, g);
+                continue;
+            }
             const long units = (long)NB * g.HW * (g.Cv / 8);
             ProfScope ps(c, s, "gn_act_kernel", 0);
             hipLaunchKernelGGL(gn_act_kernel, dim3((unsigned)((units + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, g);
@@ -2242,7 +2298,7 @@ int rdmi_destroy(rdmi_ctx* c) {
         delete T;
     }
     for (auto& q : c->progs) for (void* p : {(void*)q.d_fprog, (void*)q.d_ftabs, (void*)q.d_spill, (void*)q.d_xbuf, (void*)q.d_coop_err}) if (p) hipFree(p);
-    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all, c->t_ws, c->t_xin, c->t_out, c->d_w16};
+    void* ptrs[] = {c->d_fprog, c->d_ftabs, c->d_spill, c->d_jobs, c->d_w, c->d_int, c->ws, c->d_h1, c->d_temb, c->d_dense, c->d_s2, c->d_score, c->d_z, c->d_norms, c->d_ts, c->d_tvec, c->d_state, c->d_tt, c->d_th1, c->d_dense_all, c->t_ws, c->t_xin, c->t_out, c->d_w16, c->t_zero};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& ev : c->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     delete c;

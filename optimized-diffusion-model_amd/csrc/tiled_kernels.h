@@ -36,6 +36,7 @@ struct TConvArgs {
     float* chsum;                           // null or [n][tiles per image][Cout][2]: per-channel (sum, squared deviations about the tile mean) of this tile's outputs,
                                             // from which the consumer's GroupNorm statistics are formed (gn_finalize_kernel): no extra pass over the tensor
     int NB;
+    const void* zeros;                      // 256 zero bytes (iconv_kernel: source of window pixels outside the image)
 };
 
 __host__ __device__ inline int tconv_trv(const TConvArgs& a) { return a.ntap == 1 ? a.TR : (a.TR - 1) * a.stride + 3; }
@@ -293,7 +294,10 @@ struct GnActArgs {
     const float* stats;                     // [n][G][2] mean, rstd
     const float* gamma; const float* beta;
     bf16_t* out;                            // [n][HW][Cv]
+    bf16_t* out2;                           // null, or [n][HW][Cv]: the RAW concat rounded to bf16 (the operand of the residual block's NIN_0 shortcut)
     int NB;
+    // gn_act_fin_kernel: statistics formed in the kernel from the producers' per-tile channel records (what gn_finalize_kernel reads)
+    const float* csA; const float* csB; int tilesA, tilesB, pxA, pxB; float eps;
 };
 __global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
     const int U = a.Cv >> 3;                                   // 8-channel units per pixel
@@ -303,13 +307,15 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
     const long np = i / U;                                     // n * HW + p
     const int n = (int)(np / a.HW);
     const int Cin = a.CA + a.CB;
-    unsigned o[4];
+    unsigned o[4], o2[4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = u * 8 + h * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        o2[2 * h] = o2[2 * h + 1] = 0u;
         if (c < Cin) {
             v = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + (size_t)np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + (size_t)np * a.CB + (c - a.CA));
+            o2[2 * h] = pack_bf16x2(v[0], v[1]); o2[2 * h + 1] = pack_bf16x2(v[2], v[3]);
             const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c), bt = *reinterpret_cast<const f32x4*>(a.beta + c);
             const int g0 = c / a.Cg;
             const float m0 = a.stats[((size_t)n * a.G + g0) * 2], r0 = a.stats[((size_t)n * a.G + g0) * 2 + 1];
@@ -327,6 +333,110 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
         o[2 * h] = pack_bf16x2(v[0], v[1]); o[2 * h + 1] = pack_bf16x2(v[2], v[3]);
     }
     *reinterpret_cast<u32x4*>(a.out + (size_t)np * a.Cv + u * 8) = u32x4{o[0], o[1], o[2], o[3]};
+    if (a.out2) *reinterpret_cast<u32x4*>(a.out2 + (size_t)np * a.Cv + u * 8) = u32x4{o2[0], o2[1], o2[2], o2[3]};
+}
+
+// gn_act_kernel with gn_finalize_kernel folded in (bf16 plan: one launch per GroupNorm instead of two, no statistics tensor):
+// a workgroup owns a 64-channel slice x GA_PIX pixels of one sample and first forms (mean, rstd) of the <= 16 groups its slice
+// touches from the producing convs' per-tile channel records -- 16 work-items per group add that group's (channel, tile) records
+// in a fixed order, Chan's merge as in gn_finalize_kernel, xor-shuffles over the 16 lanes -- a few hundred bytes to a few KB of
+// L2-resident records per workgroup, brought into LDS by one round of independent loads.  Then 8 work-items per pixel normalise / activate 8 channels each: 256 B read and 128 B
+// written per pixel (full lines).  grid = (ceil(HW / GA_PIX), Cv / 64, NB).
+#define GA_PIX 128
+#define GA_MAXCH 96                                             // channels of the groups a 64-channel slice touches (Cg <= 16: 64 + 2 * 15 rounded up)
+__host__ __device__ inline size_t gn_act_fin_lds_bytes(int tiles) { return 128 + (size_t)tiles * GA_MAXCH * 2 * sizeof(float); }
+__global__ __launch_bounds__(RDMI_THREADS) void gn_act_fin_kernel(GnActArgs a) {
+    float* tab = reinterpret_cast<float*>(rdmi_lds);          // [16][2] mean, rstd of the slice's groups
+    float* rec = tab + 32;                                     // [tile][channel - lo][2]: the records of those groups' channels
+    const int tid = threadIdx.x, n = blockIdx.z;
+    const int Cin = a.CA + a.CB, c_lo = blockIdx.y * 64, c_hi = min(c_lo + 64, Cin);      // slice channels [c_lo, c_hi) (empty: padding only)
+    const int g_first = c_lo / a.Cg;
+    if (c_lo < Cin) {
+        // one round of independent loads brings the records in (a single L2 latency), the two passes then run out of LDS
+        const int lo = g_first * a.Cg, hi = min(((c_hi - 1) / a.Cg + 1) * a.Cg, Cin), nch = hi - lo;
+        const int tmax = max(a.tilesA, a.tilesB);
+        typedef float f32x2 __attribute__((vector_size(8)));
+        for (int e = tid; e < tmax * nch; e += RDMI_THREADS) {
+            const int t = e / nch, c = lo + (e - t * nch);
+            const bool inA = c < a.CA;
+            const int tiles = inA ? a.tilesA : a.tilesB;
+            f32x2 v = {0.f, 0.f};
+            if (t < tiles) v = *reinterpret_cast<const f32x2*>((inA ? a.csA : a.csB) + (((size_t)n * tiles + t) * (inA ? a.CA : a.CB) + (inA ? c : c - a.CA)) * 2);
+            *reinterpret_cast<f32x2*>(rec + (size_t)e * 2) = v;
+        }
+        __syncthreads();
+        const int slot = tid >> 4, sub = tid & 15, g = g_first + slot;
+        const bool live = g * a.Cg < c_hi && g < a.G;
+        float s1 = 0.f;
+        if (live)
+            for (int e = sub; e < a.Cg * tmax; e += 16) {
+                const int cc = e / tmax, t = e - cc * tmax;
+                s1 += rec[((size_t)t * nch + (g * a.Cg + cc - lo)) * 2];
+            }
+        for (int m = 1; m < 16; m <<= 1) s1 += __shfl_xor(s1, m);
+        const float cnt = (float)(a.Cg * a.HW);
+        const float mean = s1 / cnt;
+        float m2 = 0.f;
+        if (live)
+            for (int e = sub; e < a.Cg * tmax; e += 16) {
+                const int cc = e / tmax, t = e - cc * tmax, c = g * a.Cg + cc;
+                const bool inA = c < a.CA;
+                const int tiles = inA ? a.tilesA : a.tilesB, px = inA ? a.pxA : a.pxB;
+                if (t < tiles) {
+                    const float* p = rec + ((size_t)t * nch + (c - lo)) * 2;
+                    const float nt = (float)min(px, a.HW - t * px), d = p[0] / nt - mean;
+                    m2 += p[1] + nt * d * d;
+                }
+            }
+        for (int m = 1; m < 16; m <<= 1) m2 += __shfl_xor(m2, m);
+        if (sub == 0) { tab[slot * 2] = mean; tab[slot * 2 + 1] = 1.0f / sqrtf(m2 / cnt + a.eps); }
+    }
+    __syncthreads();
+    const int c = c_lo + (tid & 7) * 8;
+    float mean[8], rg[8], bt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mean[j] = 0.f; rg[j] = 0.f; bt[j] = 0.f;
+        if (c + j < Cin) {
+            const int slot = (c + j) / a.Cg - g_first;
+            mean[j] = tab[slot * 2]; rg[j] = tab[slot * 2 + 1] * a.gamma[c + j]; bt[j] = a.beta[c + j];
+        }
+    }
+    // the work-item's GA_PIX / 32 pixels: every load is issued before the first value is used (one memory latency per workgroup)
+    constexpr int NP = GA_PIX / (RDMI_THREADS / 8);
+    const int p0 = blockIdx.x * GA_PIX + (tid >> 3);
+    const bool lo_ok = c < Cin, hi_ok = c + 4 < Cin;
+    f32x4 v[NP][2];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = p0 + k * (RDMI_THREADS / 8);
+        const size_t np = (size_t)n * a.HW + min(p, a.HW - 1);
+        v[k][0] = v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lo_ok) v[k][0] = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c - a.CA));
+        if (hi_ok) v[k][1] = c + 4 < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c + 4) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c + 4 - a.CA));
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = p0 + k * (RDMI_THREADS / 8);
+        if (p >= a.HW) break;
+        unsigned o[4];
+        if (a.out2)         // padding channels were loaded as zero
+            *reinterpret_cast<u32x4*>(a.out2 + ((size_t)n * a.HW + p) * a.Cv + c) =
+                u32x4{pack_bf16x2(v[k][0][0], v[k][0][1]), pack_bf16x2(v[k][0][2], v[k][0][3]), pack_bf16x2(v[k][1][0], v[k][1][1]), pack_bf16x2(v[k][1][2], v[k][1][3])};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 w = v[k][h];
+            if (h == 0 ? lo_ok : hi_ok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = (w[j] - mean[h * 4 + j]) * rg[h * 4 + j] + bt[h * 4 + j];
+                    w[j] = a.act ? silu_f(y) : y;
+                }
+            }
+            o[2 * h] = pack_bf16x2(w[0], w[1]); o[2 * h + 1] = pack_bf16x2(w[2], w[3]);
+        }
+        *reinterpret_cast<u32x4*>(a.out + ((size_t)n * a.HW + p) * a.Cv + c) = u32x4{o[0], o[1], o[2], o[3]};
+    }
 }
 
 // 3x3 (stride 1, pad 1) or 1x1 conv over a bf16 tensor that is already normalised / activated (TConvArgs: srcA = that tensor,
@@ -442,6 +552,103 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
         __syncthreads();
     }
     tconv_epilogue<NMT, NCT>(a, acc, n, tile, tiles_per_img, oy0, col0, kq);
+}
+
+// ---- bf16 plan, implicit GEMM (32x32 / 16x16 / 8x8 levels at sampling batches) -------------------------------------------------
+// tconv_pre_kernel keeps a 64-pixel window in LDS and streams every weight fragment from L2 into registers: at NCT = 4 that is
+// 1 KiB of L2 traffic per 4 MFMAs and wave (64 B/clk/CU at the matrix pipe's rate -- the CU's whole L1 fill rate), and a
+// workgroup's 64 output pixels re-read all 1.2 MB of a 256 x 256 conv's weights.  iconv_kernel is the conv as a plain implicit GEMM,
+//   out[m][co] = sum_{tap, ci} act[pixel(m) + tap][ci] * W[tap][ci][co],   m = (sample, oy, ox) over the WHOLE batch,
+// on 128 x 128 output tiles with 64-deep K steps ((tap, 64-channel slab) pairs): both operand tiles go global -> LDS by the LDS-DMA
+// (glds16: no staging registers, no ds_write pass), 16 KiB each, as [row][64 bf16] images whose 16-byte chunks are XOR-swizzled
+// with (row & 7) on the SOURCE side (lane -> chunk) so that every ds_read_b128 fragment read is bank-conflict-free; each of the
+// 2 x 2 waves owns 64 x 64 outputs (4 x 4 MFMA tiles: a fragment feeds four MFMAs, half the LDS bytes per MFMA of the window
+// form, a quarter of the weight bytes per output).  The im2col gather is the per-lane source address: the tap shift and the zero
+// padding (a lane whose window pixel is outside the image reads the 16 zero bytes of a.zeros); stride 1, no upsampling.  K order: slab-major, tap-minor, so the nine taps of a slab re-read the same
+// (128 + halo) x 128 B of activations from the CU's L1.  One LDS buffer, two barriers per K step; latency is covered by the
+// 3-4 workgroups a CU holds (<= 128 VGPRs, 32 KiB of LDS each).  Epilogue = tconv_epilogue (a wave's 64 rows are one 64-pixel
+// tile of one sample: the planner's per-tile GroupNorm records keep their meaning).  Needs Ho * Wo % 64 == 0, Cout % 128 == 0,
+// Cv % 64 == 0 (host-checked).
+__host__ __device__ inline size_t iconv_lds_bytes() { return 2 * 128 * 128; }
+#ifndef RDMI_ICONV_WAVES
+#define RDMI_ICONV_WAVES 3
+#endif
+template <int NTAP>
+__global__ __launch_bounds__(RDMI_THREADS, RDMI_ICONV_WAVES) void iconv_kernel(TConvArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int HWo = a.Ho * a.Wo;
+    const long M = (long)a.NB * HWo;
+    const long m0 = (long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    // staging: this work-item copies chunk (tid & 7) of image rows (tid >> 3) + 32 j, j = 0..3, of both operand tiles; the chunk
+    // holds the tile's k = 8 * ((tid & 7) ^ (row & 7)) .. + 7.  Per row: byte offset of the window's (0, 0) tap pixel (may point
+    // before the tensor: only dereferenced where the tap's bit in `tapok` says the pixel exists) -- stride 1, no upsampling: a tap
+    // is a wave-uniform byte delta.
+    const int srow = tid >> 3;
+    const int c8 = ((tid & 7) ^ (srow & 7)) * 8;
+    long roff[4]; unsigned tapok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long gm = m0 + j * 32 + srow;
+        roff[j] = 0; tapok[j] = 0;
+        if (gm < M) {
+            const int n = (int)(gm / HWo), p = (int)(gm - (long)n * HWo);
+            const int oy = p / a.Wo, ox = p - oy * a.Wo;
+            roff[j] = (((long)n * a.Ha + (oy - a.pad_lo)) * a.Wa + (ox - a.pad_lo)) * a.Cv * 2 + c8 * 2;
+            for (int t = 0; t < NTAP; ++t) {
+                const int vy = oy - a.pad_lo + (NTAP == 9 ? t / 3 : 0), vx = ox - a.pad_lo + (NTAP == 9 ? t % 3 : 0);
+                if ((unsigned)vy < (unsigned)a.Hv && (unsigned)vx < (unsigned)a.Wv) tapok[j] |= 1u << t;
+            }
+        }
+    }
+    const char* abase = reinterpret_cast<const char*>(a.srcA);
+    const char* zsrc = reinterpret_cast<const char*>(a.zeros) + (tid & 7) * 16;
+    const int nk = a.Cv >> 5;
+    // weight source of row (column) n0 + srow + 32 j at (tap t, slab c0): block (t * nk + (c0 + c8) / 32), 64 bytes per column
+    const char* wbase = reinterpret_cast<const char*>(a.wpk) + ((size_t)(c8 >> 5) * a.Cout_pad + n0 + srow) * 64 + ((c8 >> 3) & 3) * 16;
+    const long wblk = (long)a.Cout_pad * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) acc[i][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned sw = (unsigned)(lrow & 7);
+    const unsigned aoff = (unsigned)(wr * 64 + lrow) * 128u, boff = 16384u + (unsigned)(wc * 64 + lrow) * 128u;
+    const unsigned dst = (unsigned)wave * 1024u;                   // + j * 4096 (+ 16384 for the weight tile)
+    const long rowb = (long)a.Wa * a.Cv * 2;
+    for (int c0 = 0; c0 < a.Cv; c0 += 64) {
+        for (int t = 0; t < NTAP; ++t) {
+            const int dy = NTAP == 9 ? t / 3 : 0, dx = NTAP == 9 ? t - dy * 3 : 0;
+            const long tdelta = dy * rowb + (long)(dx * a.Cv + c0) * 2;          // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16((tapok[j] >> t & 1u) ? abase + (roff[j] + tdelta) : zsrc, dst + j * 4096u);
+            const char* wsrc = wbase + ((long)t * nk + (c0 >> 5)) * wblk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(wsrc + j * 2048, 16384u + dst + j * 4096u);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned ch = ((unsigned)(ks * 4 + kq) ^ sw) * 16u;
+                u32x4 af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(rdmi_lds + aoff + i * 2048u + ch);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) bf[cc] = *reinterpret_cast<const u32x4*>(rdmi_lds + boff + cc * 2048u + ch);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[i][cc] = mfma16_bf16(af[i], bf[cc], acc[i][cc]);
+            }
+            __syncthreads();
+        }
+    }
+    const long gm0 = m0 + wr * 64;                                  // the wave's 64 rows: one 64-pixel tile of one sample
+    if (gm0 < M) {
+        const int n = (int)(gm0 / HWo), p0 = (int)(gm0 - (long)n * HWo);
+        tconv_epilogue<4, 4>(a, acc, n, p0 >> 6, HWo >> 6, p0 / a.Wo, n0 + wc * 64 + lrow, kq);
+    }
 }
 
 // GroupNorm statistics of concat(A, B) from the producers' per-tile channel records (sum, squared deviations about the tile's own

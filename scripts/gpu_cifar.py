@@ -4,6 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'optimized-diffusion-model_amd'))
 import numpy as np, torch
 import __graft_entry__ as ge
+if os.environ.get('RDMI_LIB'):
+    from rdmi import _native
+    _native.use_library(os.environ['RDMI_LIB'])
 from rdmi import sampling, sde_lib
 from rdmi.models import utils as mutils
 dev = torch.device('cuda:0')
@@ -43,5 +46,5 @@ if os.environ.get('CIFAR_PROF'):
     tot = 0
     for p_ in sorted(ctx.get_profile(), key=lambda p: -p['ms']):
         tot += p_['ms']
-        print(f"{p_['kernel']:28s} {p_['launches']:5d} launches {p_['ms']:8.3f} ms  {(p_['flops'] / (p_['ms'] * 1e-3) / 1e12) if p_['flops'] else 0:7.1f} TFLOP/s")
+        print(f"{p_['kernel']:44s} {p_['launches']:5d} launches {p_['ms']:8.3f} ms  {(p_['flops'] / (p_['ms'] * 1e-3) / 1e12) if p_['flops'] else 0:7.1f} TFLOP/s")
     print('total', tot)

@@ -611,12 +611,18 @@ def _small_rgb_model(ge, compute_dtype):
     return model.eval(), params
 
 
-@pytest.mark.parametrize('dtype,tol', [('f32', 2e-5), ('bf16', 3e-2)])
-def test_tiled_plan_small_rgb_model(emu, dtype, tol):
+@pytest.mark.parametrize('dtype,tol,iconv', [('f32', 2e-5, None), ('bf16', 3e-2, '0'), ('bf16', 3e-2, '1')])
+def test_tiled_plan_small_rgb_model(emu, dtype, tol, iconv, monkeypatch):
     """The tiled plan (csrc/tiled_kernels.h: tconv, channel-sum GroupNorm statistics, batched-GEMM attention, and for bf16 the
     pre-activated gn_act + tconv_pre pair) on the emulator against the torch oracle: classifier-free-guidance score of two samples.
-    Tolerance relative to each sample's largest |score|: fp32 2e-5; bf16 operands 3e-2 (stated bf16 tolerance, as on the GPU)."""
+    Tolerance relative to each sample's largest |score|: fp32 2e-5; bf16 operands 3e-2 (stated bf16 tolerance, as on the GPU).
+    iconv '1': the implicit-GEMM conv (iconv_kernel: LDS-DMA staged 128 x 128 tiles) is forced at this small batch (the 8x8 level's
+    128-column convs and the attention projections take it; four forwards = two row tiles), '0': switched off."""
     import __graft_entry__ as ge
+    if iconv == '1':
+        monkeypatch.setenv('RDMI_ICONV_MIN_WGS', '1')
+    elif iconv == '0':
+        monkeypatch.setenv('RDMI_ICONV', '0')
     from oracle import rd_oracle_torch as OT
     from rdmi import sde_lib
     from rdmi.models import utils as mutils
@@ -632,6 +638,13 @@ def test_tiled_plan_small_rgb_model(emu, dtype, tol):
     assert info.startswith('tiled'), info
     for n in range(2):
         assert float((s[n] - ref[n]).abs().max()) <= tol * float(ref[n].abs().max()), (n, dtype)
+    if iconv is not None:           # the forced run really took the implicit-GEMM kernel (and the other one did not)
+        ctx = model._ctx[('cpu', 16, 16)]
+        ctx.set_profiling(True)
+        with torch.no_grad():
+            mutils.get_cf_score_fn(sde, model, lab, w)(x, t)
+        names = {p['kernel']: p['launches'] for p in ctx.get_profile()}
+        assert (names.get('iconv_kernel<bf16>', 0) >= 4) == (iconv == '1'), names
 
 
 def test_tiled_plan_groupnorm_statistics_with_large_group_means(emu):
