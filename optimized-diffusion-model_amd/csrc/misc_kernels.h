@@ -20,6 +20,9 @@ struct PackJob {
     int kind;                 // 0: pack weights, 1: plain copy of Cout floats to dst + n_off, 2: pack weights as bf16 [tap][K/32][Npad][32],
                               // 3: pack the PRODUCT src (W [Cin][Cout], NIN layout) x src2 (W [Cout][Cout]), 4: the vector src (Cout floats) x src2 -> dst + n_off
     const float* src2;        // kinds 3 / 4: the right-hand factor (a NIN weight [in][out])
+    int col_il;               // kind 2, tiled plan: 0 / 1 none; F = 2 / 4: destination columns are interleaved within groups of 16 F -- column g sits at
+                              // position (g / 16F) * 16F + (g % F) * 16 + (g % 16F) / F, so that lane l of the F adjacent 16-column MFMA tiles of a
+                              // group holds the F ADJACENT output columns 16F * group + F l .. + F - 1 (tconv_epilogue's vector stores)
 };
 
 __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __restrict__ jobs) {
@@ -50,7 +53,9 @@ __global__ __launch_bounds__(RDMI_THREADS) void pack_kernel(const PackJob* __res
             const int ci = ch * 32 + kk;
             float v = 0.f;
             if (co < j.Cout && ci < j.Cin) v = j.src[co * j.s_co + ci * j.s_ci + t * j.s_t];
-            d16[(((long)t * (j.Kpad >> 5) + ch) * j.Npad + j.n_off + co) * 32 + kk] = f2bf(v);
+            int pos = j.n_off + co;
+            if (j.col_il > 1) { const int F = j.col_il, w = pos % (16 * F); pos = pos - w + (w % F) * 16 + w / F; }
+            d16[(((long)t * (j.Kpad >> 5) + ch) * j.Npad + pos) * 32 + kk] = f2bf(v);
         }
         return;
     }

@@ -191,6 +191,7 @@ struct rdmi_ctx {
     bf16_t* d_w16 = nullptr;             // bf16 copies of the forward conv weights (training with compute_dtype = bf16)
     std::vector<TLaunch> tl;
     float *t_ws = nullptr, *t_xin = nullptr, *t_out = nullptr; size_t t_ws_per_sample = 0;
+    long tiled_min_wgs = 512;                           // a tiled conv widens its workgroups (NCT column tiles per wave) while the launch keeps this many (RDMI_TILED_MIN_WGS: tests)
     long iconv_min_wgs = LONG_MAX;                      // iconv_kernel from this many 128 x 128 tiles per launch (off unless RDMI_ICONV=1 / RDMI_ICONV_MIN_WGS)
     void* t_zero = nullptr;                             // 256 zero bytes: iconv_kernel's source for window pixels outside the image
     std::vector<FusedProg> progs;
@@ -652,6 +653,15 @@ struct TiledBuilder {
         a.dense_off = dense_off < 0 ? 0 : dense_off; a.dense_stride = c->dense_total;
         a.out_scale = scale;
         a.Cout = cout; a.Cout_pad = pad16(cout);
+        // bf16 packs: interleave the weights' columns by the NCT the launch will use at the sampling batch (run_tiled's rule at 128 forwards),
+        // so that the epilogue's loads and stores are 8- / 16-byte vectors over full lines (tconv_epilogue; RDMI_NO_COL_IL=1: plain order)
+        if (bf16() && std::getenv("RDMI_NO_COL_IL") == nullptr) {
+            const long tl = ceil_div(a.Ho, a.TR);
+            for (int cand : {4, 2})
+                if (cout % (16 * cand) == 0 && a.Cout_pad >= 64 * cand && tl * 128 * ceil_div(a.Cout_pad, 64 * cand) >= 512) { a.col_il = cand; break; }
+            if (a.col_il > 1)
+                for (auto& j : c->jobs) if (j.kind == 2 && j.dst == reinterpret_cast<float*>(w_off)) j.col_il = a.col_il;
+        }
         TT out = talloc(cout, a.Ho, a.Wo);
         size_t cs_off = rdmi_ctx::TLaunch::NONE;
         if (!final_out && cout % 4 == 0) {
@@ -814,6 +824,7 @@ int finish_tiled_plan(rdmi_ctx* c) {
     HIP_OK(hipMemset(c->t_zero, 0, 256));
     // measured on MI355X (rocprofv3 kernel trace, B = 64 with guidance): 5.28 ms for the 3x3 convs of the 32x32 / 16x16 levels against 4.88 ms
     // with tconv_pre_kernel -- the implicit-GEMM form is NOT the default; RDMI_ICONV=1 selects it (from RDMI_ICONV_MIN_WGS tiles, default 256)
+    if (const char* e = std::getenv("RDMI_TILED_MIN_WGS")) c->tiled_min_wgs = std::atol(e);
     c->iconv_min_wgs = LONG_MAX;
     if (const char* e = std::getenv("RDMI_ICONV")) if (std::atoi(e) != 0) c->iconv_min_wgs = 256;
     if (const char* e = std::getenv("RDMI_ICONV_MIN_WGS")) c->iconv_min_wgs = std::atol(e);
@@ -2093,7 +2104,7 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
             // long as the launch still has >= 2 workgroups per CU
             int nct = 1;
             for (int cand : {4, 2})
-                if (ca.Cout_pad >= 64 * cand && (long)tiles * NB * ceil_div(ca.Cout_pad, 64 * cand) >= 512) { nct = cand; break; }
+                if (ca.Cout_pad >= 64 * cand && (long)tiles * NB * ceil_div(ca.Cout_pad, 64 * cand) >= c->tiled_min_wgs) { nct = cand; break; }
             dim3 grid(tiles * (unsigned)NB, (unsigned)ceil_div(ca.Cout_pad, 64 * nct));
             const bool h = a.compute_dtype == 1;
             const size_t lds = l.pre ? tconv_pre_lds_bytes(ca) : h ? tconv_bf16_lds_bytes(ca) : tconv_lds_bytes(ca);

@@ -37,6 +37,7 @@ struct TConvArgs {
                                             // from which the consumer's GroupNorm statistics are formed (gn_finalize_kernel): no extra pass over the tensor
     int NB;
     const void* zeros;                      // 256 zero bytes (iconv_kernel: source of window pixels outside the image)
+    int col_il;                             // bf16 packs: column interleave factor F of the weights (PackJob::col_il; 0 / 1: none)
 };
 
 __host__ __device__ inline int tconv_trv(const TConvArgs& a) { return a.ntap == 1 ? a.TR : (a.TR - 1) * a.stride + 3; }
@@ -142,8 +143,14 @@ __device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g
 // Per column tile the NMT * 4 residual loads are issued together BEFORE any store (with one load -> wait -> store chain per element
 // a workgroup spent 32 exposed memory latencies here: the ISA showed s_waitcnt vmcnt(0) after every load); invalid elements
 // (columns beyond Cout, rows beyond the tile / image) read offset 0 and are masked at the store.
+template <int N> struct alignas(4 * N) FVec { float v[N]; };      // N adjacent floats moved as one 8- / 16-byte access
+// Column interleave (bf16 packs, TConvArgs::col_il = F): the weights' columns are permuted within groups of 16 F so that the F adjacent
+// MFMA column tiles of a group give lane l the F ADJACENT output columns 16F g + F l .. + F - 1.  With NCT == F a lane's NCT accumulators
+// of one row are therefore one 8- or 16-byte vector: residual loads and output stores are dwordx2 / dwordx4, a wave instruction covers
+// 4 rows x 128 / 256 contiguous bytes (full lines) instead of 4 x 64 B, and there are NCT times fewer of them.  The arithmetic per
+// element and the per-column reductions are those of the scalar form (same results bit for bit).
 template <int NMT, int NCT>
-__device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, const f32x4 (&acc)[NMT][NCT], int n, int tile, int tiles_per_img, int oy0, int col0, int kq) {
+__device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, f32x4 (&acc)[NMT][NCT], int n, int tile, int tiles_per_img, int oy0, int col0, int kq) {
     float sdiv = 1.f;
     if (a.sig) {
         const float sv = a.sig[a.sig_mod > 0 ? n % a.sig_mod : n];
@@ -154,9 +161,74 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, const f32x4 (
     const size_t nbase = (size_t)n * HWo * a.Cout;             // wave-uniform sample base; element offsets below fit 32 bits
     const float* rbase = a.resid ? a.resid + nbase : nullptr;
     float* obase = a.out + nbase;
+    const int F = a.col_il > 1 ? a.col_il : 1;
+    if constexpr (NCT > 1) if (F == NCT) {
+        typedef FVec<NCT> vecF;
+        const int lrow = col0 & 15;
+        const int colb = ((col0 >> 4) / NCT) * (16 * NCT) + lrow * NCT;          // the lane's NCT adjacent columns (Cout % 16 NCT == 0: all or none exist)
+        const bool colok = colb < a.Cout;
+        float add[NCT];
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            add[cc] = (colok && a.bias) ? a.bias[colb + cc] : 0.f;
+            if (colok && a.dense) add[cc] += a.dense[(size_t)n * a.dense_stride + a.dense_off + colb + cc];
+        }
+        unsigned off[NMT][4]; bool ok[NMT][4];
+#pragma unroll
+        for (int i = 0; i < NMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i * 16 + kq * 4 + r, opix = oy0 * a.Wo + m;
+                ok[i][r] = colok && m < tile_px && opix < HWo;
+                off[i][r] = ok[i][r] ? (unsigned)(opix * a.Cout + colb) : 0u;
+            }
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
+            vecF rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (rbase) rv[r] = *reinterpret_cast<const vecF*>(rbase + off[i][r]);
+                else
+#pragma unroll
+                    for (int cc = 0; cc < NCT; ++cc) rv[r].v[cc] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vecF v;
+#pragma unroll
+                for (int cc = 0; cc < NCT; ++cc) { v.v[cc] = (acc[i][cc][r] + add[cc] + rv[r].v[cc]) * scale; acc[i][cc][r] = v.v[cc]; }
+                if (ok[i][r]) *reinterpret_cast<vecF*>(obase + off[i][r]) = v;
+            }
+        }
+        if (a.chsum) {
+            const int cnt = min(tile_px, HWo - oy0 * a.Wo);                  // valid pixels of this tile (wave-uniform)
+#pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (ok[i][r]) s1 += acc[i][cc][r];
+                s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+                const float mt = s1 / (float)cnt;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NMT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = acc[i][cc][r] - mt; if (ok[i][r]) m2 += d * d; }
+                m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+                if (kq == 0 && colok) {
+                    float* cs = a.chsum + (((size_t)n * tiles_per_img + tile) * a.Cout + colb + cc) * 2;
+                    cs[0] = s1; cs[1] = m2;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int cc = 0; cc < NCT; ++cc) {
-        const int col = col0 + cc * 16;
+        const int pos = col0 + cc * 16;                                        // position in the packed weights -> output column
+        const int col = ((pos >> 4) / F) * (16 * F) + (pos & 15) * F + (pos >> 4) % F;
         const bool colok = col < a.Cout;
         float add = (colok && a.bias) ? a.bias[col] : 0.f;
         if (colok && a.dense) add += a.dense[(size_t)n * a.dense_stride + a.dense_off + col];

@@ -611,7 +611,7 @@ def _small_rgb_model(ge, compute_dtype):
     return model.eval(), params
 
 
-@pytest.mark.parametrize('dtype,tol,iconv', [('f32', 2e-5, None), ('bf16', 3e-2, '0'), ('bf16', 3e-2, '1')])
+@pytest.mark.parametrize('dtype,tol,iconv', [('f32', 2e-5, None), ('bf16', 3e-2, '0'), ('bf16', 3e-2, '1'), ('bf16', 3e-2, 'wide')])
 def test_tiled_plan_small_rgb_model(emu, dtype, tol, iconv, monkeypatch):
     """The tiled plan (csrc/tiled_kernels.h: tconv, channel-sum GroupNorm statistics, batched-GEMM attention, and for bf16 the
     pre-activated gn_act + tconv_pre pair) on the emulator against the torch oracle: classifier-free-guidance score of two samples.
@@ -619,7 +619,9 @@ def test_tiled_plan_small_rgb_model(emu, dtype, tol, iconv, monkeypatch):
     iconv '1': the implicit-GEMM conv (iconv_kernel: LDS-DMA staged 128 x 128 tiles) is forced at this small batch (the 8x8 level's
     128-column convs and the attention projections take it; four forwards = two row tiles), '0': switched off."""
     import __graft_entry__ as ge
-    if iconv == '1':
+    if iconv == 'wide':         # the workgroup widths of a sampling batch (NCT = 2 / 4 column tiles per wave): the epilogue's vector form
+        monkeypatch.setenv('RDMI_TILED_MIN_WGS', '1')
+    elif iconv == '1':
         monkeypatch.setenv('RDMI_ICONV_MIN_WGS', '1')
     elif iconv == '0':
         monkeypatch.setenv('RDMI_ICONV', '0')
@@ -638,7 +640,7 @@ def test_tiled_plan_small_rgb_model(emu, dtype, tol, iconv, monkeypatch):
     assert info.startswith('tiled'), info
     for n in range(2):
         assert float((s[n] - ref[n]).abs().max()) <= tol * float(ref[n].abs().max()), (n, dtype)
-    if iconv is not None:           # the forced run really took the implicit-GEMM kernel (and the other one did not)
+    if iconv in ('0', '1'):         # the forced run really took the implicit-GEMM kernel (and the other one did not)
         ctx = model._ctx[('cpu', 16, 16)]
         ctx.set_profiling(True)
         with torch.no_grad():

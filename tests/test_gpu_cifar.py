@@ -230,6 +230,37 @@ def test_cifar_bf16_implicit_gemm_conv_equals_window_conv(env, golden, monkeypat
     assert np.abs(a3[:2] - a2).max() <= 2e-3 * np.abs(a2).max()        # a sample's score does not depend on the batch around it
 
 
+def test_cifar_bf16_vector_epilogue_is_bit_identical(env, golden, monkeypatch):
+    """The bf16 packs interleave their columns so that, at the workgroup widths of a sampling batch (NCT = 2 / 4 column tiles per wave,
+    forced here with RDMI_TILED_MIN_WGS=1), a lane's accumulators of one row are adjacent output columns and the conv epilogue moves
+    8- / 16-byte vectors.  Neither the interleave nor the width changes any element's arithmetic: the forward is bit-identical with
+    the plain column order (RDMI_NO_COL_IL=1) and with the narrow workgroups a small batch gets by default."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    g = golden('forward_cifar.npz')
+    dev, ge = env['dev'], env['ge']
+    sde = sde_lib.RVESDE(0.01, 50, N=1000)
+
+    def run(envvars):
+        for k, v in envvars.items():
+            monkeypatch.setenv(k, v)
+        model, cfg, _ = ge.make_cifar_model(dev, compute_dtype='bf16')
+        with torch.no_grad():
+            s = mutils.get_score_fn(sde, model)(T(g['x'], dev), T(g['t'], dev), class_labels=T(g['labels'], dev)).cpu().numpy()
+        for k in envvars:
+            monkeypatch.delenv(k)
+        return s
+    wide = run({'RDMI_TILED_MIN_WGS': '1'})
+    wide_plain = run({'RDMI_TILED_MIN_WGS': '1', 'RDMI_NO_COL_IL': '1'})
+    narrow = run({})
+    assert np.isfinite(wide).all()
+    assert np.array_equal(wide, wide_plain)
+    assert np.array_equal(wide, narrow)
+    ref = g['score']
+    for n in range(2):
+        assert np.abs(wide[n] - ref[n]).max() <= 3e-2 * np.abs(ref[n]).max()
+
+
 def test_bf16_is_refused_where_it_is_not_built(env):
     """The 9x9 GTO-Halo plans are fp32 only: asking bf16 there fails loudly instead of silently computing in fp32."""
     ge, dev = env['ge'], env['dev']
