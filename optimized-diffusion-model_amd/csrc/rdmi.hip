@@ -176,7 +176,7 @@ struct rdmi_ctx {
         const float *sA = nullptr, *sB = nullptr; int CA = 0, CB = 0, HW = 0, G = 0; float* stats = nullptr;     // kind 1
         BgemmArgs gemm{};                                                                                       // kind 2
         float* sm = nullptr; long rows_per_sample = 0; int L = 0;                                               // kind 3
-        const float* tsrc = nullptr; float* tdst = nullptr; int tL = 0, tC = 0, tld = 0, tc0 = 0;               // kind 4
+        const float* tsrc = nullptr; float* tdst = nullptr; int tL = 0, tC = 0, tld = 0, tc0 = 0; bool t16 = false;   // kind 4 (t16: bf16 elements)
         int pxA = 0, pxB = 0;                                                                                   // kind 5: pixels per full tile of each producer
         // per-sample workspace offsets (floats) of the operands, resolved to pointers by finish_tiled_plan: NONE = absent, XIN = the NHWC input copy
         static constexpr size_t NONE = (size_t)-1, XIN = (size_t)-2;
@@ -563,7 +563,7 @@ int add_resblock(Builder& b, const std::string& name, int tA, int tB, int CA, in
 struct TiledBuilder {
     rdmi_ctx* c; Builder& b;
     size_t top = 0;                                   // floats per sample allocated so far
-    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0, tile_px = 0; bool bf = false; };   // cs: per-tile channel sums of the producer; bf: a bf16 [HW][C] tensor (C % 64 == 0) for tconv_pre
+    struct TT { size_t off = 0; int C = 0, H = 0, W = 0; bool valid = false; size_t cs = (size_t)-1; int tiles = 0, tile_px = 0; bool bf = false; bool raw16 = false; };   // raw16: q | k | v stored as bf16 [HW][3C]: only the fused attention core and its V transpose read it   // cs: per-tile channel sums of the producer; bf: a bf16 [HW][C] tensor (C % 64 == 0) for tconv_pre
     TT talloc(int C, int H, int W) { TT t; t.off = top; t.C = C; t.H = H; t.W = W; t.valid = true; top += ((size_t)C * H * W + 63) & ~(size_t)63; return t; }
     static int pad32(int a) { return (a + 31) & ~31; }
 
@@ -603,7 +603,7 @@ struct TiledBuilder {
     // conv over concat(A, B) [optionally GroupNorm(+SiLU)'d with `st`], 3x3 (stride 1 pad 1 | stride 2 Downsample | nearest x2 Upsample) or 1x1
     TT conv(const std::string& name, const TT& A, const TT* B, const TT* st, const std::string& gn, bool act, int ntap, int stride, bool up,
             size_t w_off, int cout, const std::string& bias_param, size_t bias_arena, int dense_off, const TT* resid, float scale, bool final_out,
-            TT* raw_copy = nullptr) {     // raw_copy: if the conv takes the pre-activated form, its activation pass also leaves the RAW input as a bf16 [HW][Cv] tensor here
+            TT* raw_copy = nullptr, bool out16 = false) {       // out16: the output is stored as bf16 (TT::raw16)     // raw_copy: if the conv takes the pre-activated form, its activation pass also leaves the RAW input as a bf16 [HW][Cv] tensor here
         // bf16 plan: a 3x3 stride-1 conv behind a GroupNorm reads a tensor that was normalised, activated and rounded to bf16 ONCE
         // (kind 6) instead of redoing that arithmetic for every staged window element (RDMI_NO_PREACT=1: the one-kernel form)
         // (3x3 stride-1 convs and the 1x1 q/k/v projection of attention blocks); a tensor that already is bf16 (the fused attention
@@ -612,6 +612,7 @@ struct TiledBuilder {
         const bool pre = direct || (bf16() && st && (ntap == 9 || ntap == 1) && stride == 1 && !up && !final_out && cout % 16 == 0 && A.C % 4 == 0 &&
                                     (!B || B->C % 4 == 0) && (A.C + (B ? B->C : 0)) % 64 == 0 && std::getenv("RDMI_NO_PREACT") == nullptr);
         if (A.bf && !direct) throw std::runtime_error("tiled plan: a bf16 tensor feeds a conv that cannot take it (" + name + ")");
+        if (A.raw16 || (B && B->raw16) || (resid && resid->raw16)) throw std::runtime_error("tiled plan: a bf16-stored q | k | v tensor is read by a conv (" + name + ")");
         size_t act_off = A.off;
         if (pre && !direct) {
             const int Cin = A.C + (B ? B->C : 0), Cvp = pad32(Cin);
@@ -662,7 +663,8 @@ struct TiledBuilder {
             if (a.col_il > 1)
                 for (auto& j : c->jobs) if (j.kind == 2 && j.dst == reinterpret_cast<float*>(w_off)) j.col_il = a.col_il;
         }
-        TT out = talloc(cout, a.Ho, a.Wo);
+        TT out = talloc(out16 ? (cout + 1) / 2 : cout, a.Ho, a.Wo);
+        out.C = cout; out.raw16 = out16; a.out_bf16 = out16 ? 1 : 0;
         size_t cs_off = rdmi_ctx::TLaunch::NONE;
         if (!final_out && cout % 4 == 0) {
             out.tiles = ceil_div(a.Ho, a.TR); out.tile_px = a.TR * a.Wo;
@@ -718,16 +720,19 @@ struct TiledBuilder {
         }
         const size_t bq = b.alloc_w((size_t)3 * C);
         for (int i = 0; i < 3; ++i) b.job_copy(name + ".NIN_" + std::to_string(i) + ".b", bq, C, i * C);
-        TT qkv = conv(name + ".qkv", x, nullptr, &st, name + ".GroupNorm_0", false, 1, 1, false, o3, 3 * C, "", bq, -1, nullptr, 1.f, false);
-        TT Vt = talloc(C, Lq, 1);                    // [C][L]
-        TT O = talloc(C, x.H, x.W);
         const bool flash = bf16() && (C == 64 || C == 128 || C == 256) && Lq % 64 == 0 && std::getenv("RDMI_NO_FLASH") == nullptr;
+        // the fused core rounds q, k, v to bf16 before its MFMAs anyway: the projection stores them as bf16 (half the conv's writes, half the
+        // core's and the transpose's reads; same bits into the MFMAs when 1 / sqrt(C) is a power of two, C = 64 / 256).  RDMI_NO_QKV16=1: fp32
+        const bool qkv16 = flash && C % 2 == 0 && std::getenv("RDMI_NO_QKV16") == nullptr;
+        TT qkv = conv(name + ".qkv", x, nullptr, &st, name + ".GroupNorm_0", false, 1, 1, false, o3, 3 * C, "", bq, -1, nullptr, 1.f, false, nullptr, qkv16);
+        TT Vt = talloc(qkv16 ? C / 2 : C, Lq, 1);    // [C][L]
+        TT O = talloc(C, x.H, x.W);
         if (flash) { O.bf = true; }                  // written as bf16 [L][C] (half of the allocation): NIN_3 stages plain copies of it
         if (flash) {
             // bf16 plan: scores, softmax and P V in one kernel (no [L][L] buffer); V^T still comes from the transpose launch
-            { rdmi_ctx::TLaunch l; l.kind = 4; l.name = name + ".vT"; l.oA = qkv.off; l.oOut = Vt.off; l.tL = Lq; l.tC = C; l.tld = 3 * C; l.tc0 = 2 * C; c->tl.push_back(l); }
+            { rdmi_ctx::TLaunch l; l.kind = 4; l.name = name + ".vT"; l.oA = qkv.off; l.oOut = Vt.off; l.tL = Lq; l.tC = C; l.tld = 3 * C; l.tc0 = 2 * C; l.t16 = qkv16; c->tl.push_back(l); }
             rdmi_ctx::TLaunch l; l.kind = 7; l.name = name + ".core"; l.oA = qkv.off; l.oB = Vt.off; l.oOut = O.off;
-            l.flash.L = Lq; l.flash.alpha = 1.0f / std::sqrt((float)C); l.flashC = C; l.flash.out_bf16 = 1;
+            l.flash.L = Lq; l.flash.alpha = 1.0f / std::sqrt((float)C); l.flashC = C; l.flash.out_bf16 = 1; l.flash.in_bf16 = qkv16 ? 1 : 0;
             l.flops_per_sample = 4.0 * Lq * Lq * C;
             c->tl.push_back(l);
         } else {
@@ -2181,7 +2186,11 @@ int run_tiled(rdmi_ctx* c, const float* x, int x_mod, const float* sig, int sig_
         } else {
             const long n = (long)NB * l.tL * l.tC;
             ProfScope ps(c, s, "transpose_lc_kernel", 0);
-            if (l.tL % 64 == 0 && l.tC % 64 == 0)
+            if (l.t16 && l.tL % 64 == 0 && l.tC % 64 == 0)
+                hipLaunchKernelGGL(transpose_lc_tile16_kernel, dim3((unsigned)(l.tL / 64), (unsigned)(l.tC / 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s,
+                                   reinterpret_cast<const bf16_t*>(l.tsrc), reinterpret_cast<bf16_t*>(l.tdst), l.tL, l.tC, l.tld, l.tc0);
+            else if (l.t16) return fail("bf16 q | k | v: the transpose needs L and C in multiples of 64");
+            else if (l.tL % 64 == 0 && l.tC % 64 == 0)
                 hipLaunchKernelGGL(transpose_lc_tile_kernel, dim3((unsigned)(l.tL / 64), (unsigned)(l.tC / 64), (unsigned)NB), dim3(RDMI_THREADS), 0, s, l.tsrc, l.tdst, l.tL, l.tC, l.tld, l.tc0);
             else
             hipLaunchKernelGGL(transpose_lc_kernel, dim3((unsigned)((n + RDMI_THREADS - 1) / RDMI_THREADS)), dim3(RDMI_THREADS), 0, s, l.tsrc, l.tdst, NB, l.tL, l.tC, l.tld, l.tc0);

@@ -38,6 +38,7 @@ struct TConvArgs {
     int NB;
     const void* zeros;                      // 256 zero bytes (iconv_kernel: source of window pixels outside the image)
     int col_il;                             // bf16 packs: column interleave factor F of the weights (PackJob::col_il; 0 / 1: none)
+    int out_bf16;                           // 1: `out` is a bf16 [n][Ho*Wo][Cout] tensor (the q | k | v projection feeding flash_attn_bf16_kernel, which rounds to bf16 anyway)
 };
 
 __host__ __device__ inline int tconv_trv(const TConvArgs& a) { return a.ntap == 1 ? a.TR : (a.TR - 1) * a.stride + 3; }
@@ -197,7 +198,13 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, f32x4 (&acc)[
                 vecF v;
 #pragma unroll
                 for (int cc = 0; cc < NCT; ++cc) { v.v[cc] = (acc[i][cc][r] + add[cc] + rv[r].v[cc]) * scale; acc[i][cc][r] = v.v[cc]; }
-                if (ok[i][r]) *reinterpret_cast<vecF*>(obase + off[i][r]) = v;
+                if (ok[i][r]) {
+                    if (a.out_bf16) {
+                        bf16_t* o16 = reinterpret_cast<bf16_t*>(a.out) + nbase + off[i][r];
+                        if constexpr (NCT == 4) { typedef unsigned int u32x2 __attribute__((vector_size(8))); *reinterpret_cast<u32x2*>(o16) = u32x2{pack_bf16x2(v.v[0], v.v[1]), pack_bf16x2(v.v[2], v.v[3])}; }
+                        else *reinterpret_cast<unsigned*>(o16) = pack_bf16x2(v.v[0], v.v[1]);
+                    } else *reinterpret_cast<vecF*>(obase + off[i][r]) = v;
+                }
             }
         }
         if (a.chsum) {
@@ -256,7 +263,7 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, f32x4 (&acc)[
             for (int r = 0; r < 4; ++r) {
                 const float v = (acc[i][cc][r] + add + rv[i][r]) * scale;
                 vals[i][r] = v;
-                if (ok[i][r]) { obase[off[i][r]] = v; s1 += v; }
+                if (ok[i][r]) { if (a.out_bf16) reinterpret_cast<bf16_t*>(a.out)[nbase + off[i][r]] = f2bf(v); else obase[off[i][r]] = v; s1 += v; }
             }
         if (a.chsum) {
             // per (sample, tile, column): the sum of the tile's outputs and their squared deviations about the TILE's own mean (no
@@ -888,7 +895,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void softmax_rows_kernel(float* __res
 //   that same order (two ds_read_b64), so P goes from accumulator to operand with a bf16 conversion only.
 // K blocks of 64 keys are staged as [key][C + 8] bf16, V^T blocks (from the [C][L] transpose the plan already makes) as
 // [channel][64 + 8] bf16; fp32 running max / sum / output accumulators.
-struct FlashArgs { const float* qkv; const float* vt; float* out; int L, NB; float alpha; int out_bf16; };   // qkv [n][L][3C] (q | k | v), vt [n][C][L], out [n][L][C] (fp32, or bf16 for a tconv_pre consumer)
+struct FlashArgs { const float* qkv; const float* vt; float* out; int L, NB; float alpha; int out_bf16; int in_bf16; };     // in_bf16: qkv and vt hold bf16 (same element layout)   // qkv [n][L][3C] (q | k | v), vt [n][C][L], out [n][L][C] (fp32, or bf16 for a tconv_pre consumer)
 template <int C>
 __host__ __device__ inline size_t flash_lds_bytes() { return ((size_t)64 * (C + 8) + (size_t)C * 72) * 2; }
 
@@ -899,14 +906,16 @@ __global__ __launch_bounds__(RDMI_THREADS) void flash_attn_bf16_kernel(FlashArgs
     const int n = blockIdx.y, q = blockIdx.x * 64 + wave * 16 + l15;
     bf16_t* Kl = reinterpret_cast<bf16_t*>(rdmi_lds);        // [64][KR]
     bf16_t* Vl = Kl + 64 * KR;                                // [C][VR]
-    const float* qkv = a.qkv + (size_t)n * a.L * 3 * C;
-    const float* vt = a.vt + (size_t)n * C * a.L;
+    const float* qkv = a.qkv + (a.in_bf16 ? (size_t)n * a.L * 3 * C / 2 : (size_t)n * a.L * 3 * C);
+    const float* vt = a.vt + (a.in_bf16 ? (size_t)n * C * a.L / 2 : (size_t)n * C * a.L);
+    const bf16_t* qkv16 = reinterpret_cast<const bf16_t*>(qkv);
+    const bf16_t* vt16 = reinterpret_cast<const bf16_t*>(vt);
     // this lane's query fragments (B operand): channels 32 s + 8 g .. + 7, pre-scaled by 1 / sqrt(C)
     u32x4 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(qkv + (size_t)q * 3 * C + 32 * s + 8 * g);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(qkv + (size_t)q * 3 * C + 32 * s + 8 * g + 4);
+        const f32x4 v0 = ldact4(qkv, (size_t)q * 3 * C + 32 * s + 8 * g, a.in_bf16);
+        const f32x4 v1 = ldact4(qkv, (size_t)q * 3 * C + 32 * s + 8 * g + 4, a.in_bf16);
         qf[s] = u32x4{pack_bf16x2(v0[0] * a.alpha, v0[1] * a.alpha), pack_bf16x2(v0[2] * a.alpha, v0[3] * a.alpha),
                       pack_bf16x2(v1[0] * a.alpha, v1[1] * a.alpha), pack_bf16x2(v1[2] * a.alpha, v1[3] * a.alpha)};
     }
@@ -920,12 +929,14 @@ __global__ __launch_bounds__(RDMI_THREADS) void flash_attn_bf16_kernel(FlashArgs
 #pragma unroll 4
         for (int it = 0; it < C / 16; ++it) {                  // K block: 64 keys x C channels (4 loads in flight: the accumulators need the registers)
             const int idx = tid + it * RDMI_THREADS, key = idx / (C / 4), c4 = idx - key * (C / 4);
+            if (a.in_bf16) { *reinterpret_cast<u32x2*>(Kl + key * KR + 4 * c4) = *reinterpret_cast<const u32x2*>(qkv16 + (size_t)(kb + key) * 3 * C + C + 4 * c4); continue; }
             const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (size_t)(kb + key) * 3 * C + C + 4 * c4);
             *reinterpret_cast<u32x2*>(Kl + key * KR + 4 * c4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
 #pragma unroll 4
         for (int it = 0; it < C / 16; ++it) {                  // V^T block: C channels x 64 keys
             const int idx = tid + it * RDMI_THREADS, c = idx >> 4, k4 = idx & 15;
+            if (a.in_bf16) { *reinterpret_cast<u32x2*>(Vl + c * VR + 4 * k4) = *reinterpret_cast<const u32x2*>(vt16 + (size_t)c * a.L + kb + 4 * k4); continue; }
             const f32x4 v = *reinterpret_cast<const f32x4*>(vt + (size_t)c * a.L + kb + 4 * k4);
             *reinterpret_cast<u32x2*>(Vl + c * VR + 4 * k4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
@@ -1007,6 +1018,18 @@ __global__ __launch_bounds__(RDMI_THREADS) void transpose_lc_tile_kernel(const f
     __syncthreads();
 #pragma unroll 4
     for (int r = ty; r < 64; r += 4) dst[((size_t)n * C + cb + r) * L + l0 + tx] = tile[tx][r];
+}
+
+// the same 64 x 64 tile transpose over bf16 tensors (q | k | v stored as bf16 for the fused attention core)
+__global__ __launch_bounds__(RDMI_THREADS) void transpose_lc_tile16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int L, int C, int ld, int c0) {
+    __shared__ bf16_t tile16[64][66];
+    const int l0 = blockIdx.x * 64, cb = blockIdx.y * 64, n = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) tile16[r][tx] = src[((size_t)n * L + l0 + r) * ld + c0 + cb + tx];
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) dst[((size_t)n * C + cb + r) * L + l0 + tx] = tile16[tx][r];
 }
 
 // API boundary for channels > 1: NCHW (the reference's layout) <-> NHWC

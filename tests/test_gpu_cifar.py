@@ -234,7 +234,8 @@ def test_cifar_bf16_vector_epilogue_is_bit_identical(env, golden, monkeypatch):
     """The bf16 packs interleave their columns so that, at the workgroup widths of a sampling batch (NCT = 2 / 4 column tiles per wave,
     forced here with RDMI_TILED_MIN_WGS=1), a lane's accumulators of one row are adjacent output columns and the conv epilogue moves
     8- / 16-byte vectors.  Neither the interleave nor the width changes any element's arithmetic: the forward is bit-identical with
-    the plain column order (RDMI_NO_COL_IL=1) and with the narrow workgroups a small batch gets by default."""
+    the plain column order (RDMI_NO_COL_IL=1) and with the narrow workgroups a small batch gets by default.  Likewise the bf16 storage of
+    the attention blocks' q | k | v projection (the fused core rounds them to bf16 anyway) against fp32 storage (RDMI_NO_QKV16=1)."""
     from rdmi import sde_lib
     from rdmi.models import utils as mutils
     g = golden('forward_cifar.npz')
@@ -253,9 +254,13 @@ def test_cifar_bf16_vector_epilogue_is_bit_identical(env, golden, monkeypatch):
     wide = run({'RDMI_TILED_MIN_WGS': '1'})
     wide_plain = run({'RDMI_TILED_MIN_WGS': '1', 'RDMI_NO_COL_IL': '1'})
     narrow = run({})
+    qkv32 = run({'RDMI_NO_QKV16': '1'})
     assert np.isfinite(wide).all()
     assert np.array_equal(wide, wide_plain)
     assert np.array_equal(wide, narrow)
+    # q | k | v stored as bf16 by the projection (default) or as fp32 and rounded by the attention core: the same bits reach the MFMAs
+    # (1 / sqrt(256) is a power of two, so scaling q commutes with the rounding)
+    assert np.array_equal(narrow, qkv32)
     ref = g['score']
     for n in range(2):
         assert np.abs(wide[n] - ref[n]).max() <= 3e-2 * np.abs(ref[n]).max()
