@@ -183,21 +183,24 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, f32x4 (&acc)[
                 ok[i][r] = colok && m < tile_px && opix < HWo;
                 off[i][r] = ok[i][r] ? (unsigned)(opix * a.Cout + colb) : 0u;
             }
+        // every residual vector of the wave's tile is requested before the first store (one memory round trip, as in the scalar form)
+        vecF rv[NMT][4];
 #pragma unroll
-        for (int i = 0; i < NMT; ++i) {
-            vecF rv[4];
+        for (int i = 0; i < NMT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (rbase) rv[r] = *reinterpret_cast<const vecF*>(rbase + off[i][r]);
+                if (rbase) rv[i][r] = *reinterpret_cast<const vecF*>(rbase + off[i][r]);
                 else
 #pragma unroll
-                    for (int cc = 0; cc < NCT; ++cc) rv[r].v[cc] = 0.f;
+                    for (int cc = 0; cc < NCT; ++cc) rv[i][r].v[cc] = 0.f;
             }
+#pragma unroll
+        for (int i = 0; i < NMT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 vecF v;
 #pragma unroll
-                for (int cc = 0; cc < NCT; ++cc) { v.v[cc] = (acc[i][cc][r] + add[cc] + rv[r].v[cc]) * scale; acc[i][cc][r] = v.v[cc]; }
+                for (int cc = 0; cc < NCT; ++cc) { v.v[cc] = (acc[i][cc][r] + add[cc] + rv[i][r].v[cc]) * scale; acc[i][cc][r] = v.v[cc]; }
                 if (ok[i][r]) {
                     if (a.out_bf16) {
                         bf16_t* o16 = reinterpret_cast<bf16_t*>(a.out) + nbase + off[i][r];
@@ -419,8 +422,8 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_kernel(GnActArgs a) {
 // a workgroup owns a 64-channel slice x GA_PIX pixels of one sample and first forms (mean, rstd) of the <= 16 groups its slice
 // touches from the producing convs' per-tile channel records -- 16 work-items per group add that group's (channel, tile) records
 // in a fixed order, Chan's merge as in gn_finalize_kernel, xor-shuffles over the 16 lanes -- a few hundred bytes to a few KB of
-// L2-resident records per workgroup, brought into LDS by one round of independent loads.  Then 8 work-items per pixel normalise / activate 8 channels each: 256 B read and 128 B
-// written per pixel (full lines).  grid = (ceil(HW / GA_PIX), Cv / 64, NB).
+// L2-resident records per workgroup, brought into LDS by one round of independent loads.  Then 16 work-items per pixel normalise / activate 4 channels each: 256 B read and 128 B
+// written per pixel (full lines per wave instruction).  grid = (ceil(HW / GA_PIX), Cv / 64, NB).
 #define GA_PIX 128
 #define GA_MAXCH 96                                             // channels of the groups a 64-channel slice touches (Cg <= 16: 64 + 2 * 15 rounded up)
 __host__ __device__ inline size_t gn_act_fin_lds_bytes(int tiles) { return 128 + (size_t)tiles * GA_MAXCH * 2 * sizeof(float); }
@@ -471,50 +474,43 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_fin_kernel(GnActArgs a) {
         if (sub == 0) { tab[slot * 2] = mean; tab[slot * 2 + 1] = 1.0f / sqrtf(m2 / cnt + a.eps); }
     }
     __syncthreads();
-    const int c = c_lo + (tid & 7) * 8;
-    float mean[8], rg[8], bt[8];
+    // 16 work-items per pixel, 4 channels each: a wave instruction reads whole 256-byte pixel rows of the slice (full lines) and writes
+    // whole 128-byte rows; the work-item's GA_PIX / 16 pixels are all loaded before the first value is used (one memory latency)
+    const int c = c_lo + (tid & 15) * 4;
+    const bool c_ok = c < Cin;
+    float mean[4], rg[4], bt[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
         mean[j] = 0.f; rg[j] = 0.f; bt[j] = 0.f;
         if (c + j < Cin) {
             const int slot = (c + j) / a.Cg - g_first;
             mean[j] = tab[slot * 2]; rg[j] = tab[slot * 2 + 1] * a.gamma[c + j]; bt[j] = a.beta[c + j];
         }
     }
-    // the work-item's GA_PIX / 32 pixels: every load is issued before the first value is used (one memory latency per workgroup)
-    constexpr int NP = GA_PIX / (RDMI_THREADS / 8);
-    const int p0 = blockIdx.x * GA_PIX + (tid >> 3);
-    const bool lo_ok = c < Cin, hi_ok = c + 4 < Cin;
-    f32x4 v[NP][2];
+    constexpr int PP = RDMI_THREADS / 16, NP = GA_PIX / PP;
+    const int p0 = blockIdx.x * GA_PIX + (tid >> 4);
+    f32x4 v[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int p = p0 + k * (RDMI_THREADS / 8);
-        const size_t np = (size_t)n * a.HW + min(p, a.HW - 1);
-        v[k][0] = v[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lo_ok) v[k][0] = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c - a.CA));
-        if (hi_ok) v[k][1] = c + 4 < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c + 4) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c + 4 - a.CA));
+        const size_t np = (size_t)n * a.HW + min(p0 + k * PP, a.HW - 1);
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c_ok) v[k] = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c - a.CA));
     }
+    typedef unsigned int u32x2 __attribute__((vector_size(8)));
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int p = p0 + k * (RDMI_THREADS / 8);
+        const int p = p0 + k * PP;
         if (p >= a.HW) break;
-        unsigned o[4];
-        if (a.out2)         // padding channels were loaded as zero
-            *reinterpret_cast<u32x4*>(a.out2 + ((size_t)n * a.HW + p) * a.Cv + c) =
-                u32x4{pack_bf16x2(v[k][0][0], v[k][0][1]), pack_bf16x2(v[k][0][2], v[k][0][3]), pack_bf16x2(v[k][1][0], v[k][1][1]), pack_bf16x2(v[k][1][2], v[k][1][3])};
+        f32x4 w = v[k];
+        if (a.out2) *reinterpret_cast<u32x2*>(a.out2 + ((size_t)n * a.HW + p) * a.Cv + c) = u32x2{pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3])};     // padding channels were loaded as zero
+        if (c_ok) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x4 w = v[k][h];
-            if (h == 0 ? lo_ok : hi_ok) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = (w[j] - mean[h * 4 + j]) * rg[h * 4 + j] + bt[h * 4 + j];
-                    w[j] = a.act ? silu_f(y) : y;
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float y = (w[j] - mean[j]) * rg[j] + bt[j];
+                w[j] = a.act ? silu_f(y) : y;
             }
-            o[2 * h] = pack_bf16x2(w[0], w[1]); o[2 * h + 1] = pack_bf16x2(w[2], w[3]);
         }
-        *reinterpret_cast<u32x4*>(a.out + ((size_t)n * a.HW + p) * a.Cv + c) = u32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<u32x2*>(a.out + ((size_t)n * a.HW + p) * a.Cv + c) = u32x2{pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3])};
     }
 }
 
