@@ -183,30 +183,36 @@ __device__ __forceinline__ void tconv_epilogue(const TConvArgs& a, f32x4 (&acc)[
                 ok[i][r] = colok && m < tile_px && opix < HWo;
                 off[i][r] = ok[i][r] ? (unsigned)(opix * a.Cout + colb) : 0u;
             }
-        // every residual vector of the wave's tile is requested before the first store (one memory round trip, as in the scalar form)
-        vecF rv[NMT][4];
+        // every residual vector of the wave's tile is requested before the first store (one memory round trip, as in the scalar form;
+        // two halves of 32 registers each let the NCT = 4 kernel hold a third wave per SIMD and measured no faster)
+        constexpr int IH = NMT;
 #pragma unroll
-        for (int i = 0; i < NMT; ++i)
+        for (int i0 = 0; i0 < NMT; i0 += IH) {
+            vecF rv[IH][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (rbase) rv[i][r] = *reinterpret_cast<const vecF*>(rbase + off[i][r]);
-                else
+            for (int i = 0; i < IH; ++i)
 #pragma unroll
-                    for (int cc = 0; cc < NCT; ++cc) rv[i][r].v[cc] = 0.f;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    if (rbase) rv[i][r] = *reinterpret_cast<const vecF*>(rbase + off[i0 + i][r]);
+                    else
 #pragma unroll
-        for (int i = 0; i < NMT; ++i) {
+                        for (int cc = 0; cc < NCT; ++cc) rv[i][r].v[cc] = 0.f;
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                vecF v;
+            for (int ii = 0; ii < IH; ++ii) {
+                const int i = i0 + ii;
 #pragma unroll
-                for (int cc = 0; cc < NCT; ++cc) { v.v[cc] = (acc[i][cc][r] + add[cc] + rv[i][r].v[cc]) * scale; acc[i][cc][r] = v.v[cc]; }
-                if (ok[i][r]) {
-                    if (a.out_bf16) {
-                        bf16_t* o16 = reinterpret_cast<bf16_t*>(a.out) + nbase + off[i][r];
-                        if constexpr (NCT == 4) { typedef unsigned int u32x2 __attribute__((vector_size(8))); *reinterpret_cast<u32x2*>(o16) = u32x2{pack_bf16x2(v.v[0], v.v[1]), pack_bf16x2(v.v[2], v.v[3])}; }
-                        else *reinterpret_cast<unsigned*>(o16) = pack_bf16x2(v.v[0], v.v[1]);
-                    } else *reinterpret_cast<vecF*>(obase + off[i][r]) = v;
+                for (int r = 0; r < 4; ++r) {
+                    vecF v;
+#pragma unroll
+                    for (int cc = 0; cc < NCT; ++cc) { v.v[cc] = (acc[i][cc][r] + add[cc] + rv[ii][r].v[cc]) * scale; acc[i][cc][r] = v.v[cc]; }
+                    if (ok[i][r]) {
+                        if (a.out_bf16) {
+                            bf16_t* o16 = reinterpret_cast<bf16_t*>(a.out) + nbase + off[i][r];
+                            if constexpr (NCT == 4) { typedef unsigned int u32x2 __attribute__((vector_size(8))); *reinterpret_cast<u32x2*>(o16) = u32x2{pack_bf16x2(v.v[0], v.v[1]), pack_bf16x2(v.v[2], v.v[3])}; }
+                            else *reinterpret_cast<unsigned*>(o16) = pack_bf16x2(v.v[0], v.v[1]);
+                        } else *reinterpret_cast<vecF*>(obase + off[i][r]) = v;
+                    }
                 }
             }
         }
@@ -604,9 +610,16 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
     // ring depth: the loads of group j + RING - 1 are issued before the MFMAs of group j (an L2 hit takes 500-800 cycles, a group
     // of NMT * NCT MFMAs 128-256): deeper for the narrow column tiles, whose groups are short and whose fragments are few registers
     constexpr int RING = NCT >= 4 ? 4 : 6, AHEAD = RING - 1;
-    fetch(0);
+    // the next slab's window is register-prefetched under this slab's MFMAs only where that does not cost a wave per SIMD (PF; measured:
+    // narrow tiles gain more from a fourth wave than from the prefetch)
+#ifndef RDMI_TPRE_PF
+#define RDMI_TPRE_PF(NCT) ((NCT) >= 4)
+#endif
+    constexpr bool PF = RDMI_TPRE_PF(NCT);
+    if (PF) fetch(0);
     for (int c0 = 0; c0 < a.Cv; c0 += KS) {
         u32x4 br[RING][NCT];
+        if (!PF) fetch(c0);
 #pragma unroll
         for (int j = 0; j < AHEAD; ++j)
             if (j < GROUPS) loadB(j, c0, br[j]);
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
             if (i < npix * UPP) *reinterpret_cast<u32x4*>(win + (size_t)(i / UPP) * ROW + u8) = raw[k];
         }
         __syncthreads();
-        if (c0 + KS < a.Cv) fetch(c0 + KS);                    // next slab's loads fly under this slab's MFMAs
+        if (PF && c0 + KS < a.Cv) fetch(c0 + KS);              // next slab's loads fly under this slab's MFMAs
         const int ksteps = min(KSTEPS, nk - (c0 >> 5));
 #pragma unroll
         for (int j = 0; j < GROUPS; ++j) {
