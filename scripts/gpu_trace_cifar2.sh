@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the CIFAR-shape bf16 score evaluation (B = 64 with guidance), aggregated per (kernel, grid), for two plans:
-# default (iconv + folded GroupNorm) and RDMI_ICONV=0
+# tag "on": default plan; tag "off": RDMI_ICONV=0 (identical now that the implicit-GEMM conv is off by default; TAGS selects)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export CIFAR_DTYPE=bf16 CIFAR_PROF=64
-for tag in on off; do
+for tag in ${TAGS:-on off}; do
   O=gpurun_out/trc_$tag; rm -rf $O; mkdir -p $O
   if [ $tag = off ]; then export RDMI_ICONV=0; fi
   rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python3 scripts/gpu_cifar.py > $O/out.log 2>&1 || { echo "rocprof failed"; tail -5 $O/out.log; exit 1; }
