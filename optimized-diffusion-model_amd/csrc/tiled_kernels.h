@@ -936,19 +936,31 @@ __global__ __launch_bounds__(RDMI_THREADS) void flash_attn_bf16_kernel(FlashArgs
     typedef unsigned int u32x2 __attribute__((vector_size(8)));
     for (int kb = 0; kb < a.L; kb += 64) {
         __syncthreads();                                       // previous block fully consumed
+        if (a.in_bf16) {
+            // bf16 q | k | v: both blocks are plain 16-byte copies (half the instructions of the fp32 form, no conversion)
+#pragma unroll 4
+            for (int it = 0; it < C / 32; ++it) {              // K block: 64 keys x C channels
+                const int idx = tid + it * RDMI_THREADS, key = idx / (C / 8), c8 = idx - key * (C / 8);
+                *reinterpret_cast<u32x4*>(Kl + key * KR + 8 * c8) = *reinterpret_cast<const u32x4*>(qkv16 + (size_t)(kb + key) * 3 * C + C + 8 * c8);
+            }
+#pragma unroll 4
+            for (int it = 0; it < C / 32; ++it) {              // V^T block: C channels x 64 keys
+                const int idx = tid + it * RDMI_THREADS, c = idx >> 3, k8 = idx & 7;
+                *reinterpret_cast<u32x4*>(Vl + c * VR + 8 * k8) = *reinterpret_cast<const u32x4*>(vt16 + (size_t)c * a.L + kb + 8 * k8);
+            }
+        } else {
 #pragma unroll 4
         for (int it = 0; it < C / 16; ++it) {                  // K block: 64 keys x C channels (4 loads in flight: the accumulators need the registers)
             const int idx = tid + it * RDMI_THREADS, key = idx / (C / 4), c4 = idx - key * (C / 4);
-            if (a.in_bf16) { *reinterpret_cast<u32x2*>(Kl + key * KR + 4 * c4) = *reinterpret_cast<const u32x2*>(qkv16 + (size_t)(kb + key) * 3 * C + C + 4 * c4); continue; }
             const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (size_t)(kb + key) * 3 * C + C + 4 * c4);
             *reinterpret_cast<u32x2*>(Kl + key * KR + 4 * c4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
 #pragma unroll 4
         for (int it = 0; it < C / 16; ++it) {                  // V^T block: C channels x 64 keys
             const int idx = tid + it * RDMI_THREADS, c = idx >> 4, k4 = idx & 15;
-            if (a.in_bf16) { *reinterpret_cast<u32x2*>(Vl + c * VR + 4 * k4) = *reinterpret_cast<const u32x2*>(vt16 + (size_t)c * a.L + kb + 4 * k4); continue; }
             const f32x4 v = *reinterpret_cast<const f32x4*>(vt + (size_t)c * a.L + kb + 4 * k4);
             *reinterpret_cast<u32x2*>(Vl + c * VR + 4 * k4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
         }
         __syncthreads();
         // S^T: four key tiles x KS k-steps
