@@ -266,6 +266,52 @@ def test_cifar_bf16_vector_epilogue_is_bit_identical(env, golden, monkeypatch):
         assert np.abs(wide[n] - ref[n]).max() <= 3e-2 * np.abs(ref[n]).max()
 
 
+def test_cifar_bf16_bench_batch_against_fp32_plan(env):
+    """The bf16 plan at the batch `bench.py` times (`variants.cifar_b64_bf16`: B = 64 with guidance = 128 forwards per launch, where the
+    convs run their wide workgroups -- 2 / 4 column tiles per wave, the vector epilogue over interleaved weight columns -- the activation
+    pass folds the GroupNorm statistics and the attention core reads bf16 q | k | v) against the fp32 plan on the same inputs.  The fp32
+    plan is the parity reference (pinned to the reference-recorded forward at 2e-5 above); stated bf16 tolerance as everywhere: 3e-2 of
+    each sample's largest |score| at the maximum, 6e-3 in the root-mean-square, both scaled by (1 + 2 w) for the guidance combination.
+    At the time of update 700 of the real 1000-scale schedule the score difference times g(t)^2/N (what a reflected PC update adds to x)
+    stays within 2e-5 + 3e-2 g(t)^2/N max|score|."""
+    from rdmi import sde_lib
+    from rdmi.models import utils as mutils
+    dev, ge = env['dev'], env['ge']
+    m16, _, _ = ge.make_cifar_model(dev, compute_dtype='bf16')
+    m32 = env['model']
+    B, N = 64, 1000
+    sde = sde_lib.RVESDE(0.01, 50, N=N)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(B, 3, 32, 32, generator=g).to(dev); lab = torch.zeros(B, 1, device=dev); w = torch.rand(B, generator=g).to(dev)
+    t = (torch.rand(B, generator=g) * 0.9 + 0.05).to(dev)
+    with torch.no_grad():
+        s16 = mutils.get_cf_score_fn(sde, m16, lab, w)(x, t).cpu()
+        s32 = mutils.get_cf_score_fn(sde, m32, lab, w)(x, t).cpu()
+    info = m16._ctx[(str(dev), 32, 32)].path_info()
+    assert 'bf16' in info and 'tiled' in info, info
+    assert torch.isfinite(s16).all()
+    worst = 0.0
+    for n in range(B):
+        d = s16[n] - s32[n]
+        amp = float(s32[n].abs().max()) * (1 + 2 * float(w[n]))
+        assert float(d.abs().max()) <= 3e-2 * amp, (n, float(d.abs().max()) / amp)
+        assert float((d ** 2).mean().sqrt()) <= 6e-3 * amp, n
+        worst = max(worst, float(d.abs().max()) / amp)
+    assert worst > 1e-5          # not a silent fp32 run
+    # the same at ONE time of the real schedule (update 700), as a PC update sees it: x' = reflect(x + g^2/N * score + g/sqrt(N) z), so the
+    # two plans' updates from one state and one noise draw differ by g^2/N times their score difference
+    i = 700
+    ts = torch.linspace(1, 1e-5, N)
+    tv = torch.full((B,), float(ts[i]), device=dev)
+    with torch.no_grad():
+        sc16 = mutils.get_cf_score_fn(sde, m16, lab, w)(x, tv).cpu()
+        sc32 = mutils.get_cf_score_fn(sde, m32, lab, w)(x, tv).cpu()
+    from oracle import rd_oracle_torch as OT
+    gg = float(OT.g_of(tv[:1].cpu(), smax=50.0)[0]) ** 2 / N
+    amp = float(sc32.abs().max()) * 3
+    assert float((sc16 - sc32).abs().max()) * gg <= 2e-5 + 3e-2 * gg * amp
+
+
 def test_bf16_is_refused_where_it_is_not_built(env):
     """The 9x9 GTO-Halo plans are fp32 only: asking bf16 there fails loudly instead of silently computing in fp32."""
     ge, dev = env['ge'], env['dev']
