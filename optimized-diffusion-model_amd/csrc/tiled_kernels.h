@@ -439,6 +439,20 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_fin_kernel(GnActArgs a) {
     const int tid = threadIdx.x, n = blockIdx.z;
     const int Cin = a.CA + a.CB, c_lo = blockIdx.y * 64, c_hi = min(c_lo + 64, Cin);      // slice channels [c_lo, c_hi) (empty: padding only)
     const int g_first = c_lo / a.Cg;
+    // 16 work-items per pixel, 4 channels each: a wave instruction reads whole 256-byte pixel rows of the slice (full lines) and writes
+    // whole 128-byte rows.  The work-item's GA_PIX / 16 pixels are requested FIRST -- they do not depend on the statistics, so the
+    // tensor streams in while the records are fetched and merged below
+    const int c = c_lo + (tid & 15) * 4;
+    const bool c_ok = c < Cin;
+    constexpr int PP = RDMI_THREADS / 16, NP = GA_PIX / PP;
+    const int p0 = blockIdx.x * GA_PIX + (tid >> 4);
+    f32x4 v[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const size_t np = (size_t)n * a.HW + min(p0 + k * PP, a.HW - 1);
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c_ok) v[k] = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c - a.CA));
+    }
     if (c_lo < Cin) {
         // one round of independent loads brings the records in (a single L2 latency), the two passes then run out of LDS
         const int lo = g_first * a.Cg, hi = min(((c_hi - 1) / a.Cg + 1) * a.Cg, Cin), nch = hi - lo;
@@ -480,10 +494,6 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_fin_kernel(GnActArgs a) {
         if (sub == 0) { tab[slot * 2] = mean; tab[slot * 2 + 1] = 1.0f / sqrtf(m2 / cnt + a.eps); }
     }
     __syncthreads();
-    // 16 work-items per pixel, 4 channels each: a wave instruction reads whole 256-byte pixel rows of the slice (full lines) and writes
-    // whole 128-byte rows; the work-item's GA_PIX / 16 pixels are all loaded before the first value is used (one memory latency)
-    const int c = c_lo + (tid & 15) * 4;
-    const bool c_ok = c < Cin;
     float mean[4], rg[4], bt[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -492,15 +502,6 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_fin_kernel(GnActArgs a) {
             const int slot = (c + j) / a.Cg - g_first;
             mean[j] = tab[slot * 2]; rg[j] = tab[slot * 2 + 1] * a.gamma[c + j]; bt[j] = a.beta[c + j];
         }
-    }
-    constexpr int PP = RDMI_THREADS / 16, NP = GA_PIX / PP;
-    const int p0 = blockIdx.x * GA_PIX + (tid >> 4);
-    f32x4 v[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const size_t np = (size_t)n * a.HW + min(p0 + k * PP, a.HW - 1);
-        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c_ok) v[k] = c < a.CA ? *reinterpret_cast<const f32x4*>(a.A + np * a.CA + c) : *reinterpret_cast<const f32x4*>(a.B + np * a.CB + (c - a.CA));
     }
     typedef unsigned int u32x2 __attribute__((vector_size(8)));
 #pragma unroll
