@@ -611,10 +611,9 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
     // ring depth: the loads of group j + RING - 1 are issued before the MFMAs of group j (an L2 hit takes 500-800 cycles, a group
     // of NMT * NCT MFMAs 128-256): deeper for the narrow column tiles, whose groups are short and whose fragments are few registers
     constexpr int RING = NCT >= 4 ? 4 : 6, AHEAD = RING - 1;
-    // the next slab's window is register-prefetched under this slab's MFMAs only where that does not cost a wave per SIMD (PF).  Registers are
-    // VGPRs + the accumulators' AGPRs: NCT = 2 needs 150 + 32 with the prefetch (2 waves per SIMD) and 127 + 32 without (3 waves) and measured
-    // faster without; NCT = 1 (110 + 16) holds 4 waves either way; NCT = 4 (184 + 64 = 248) is bound to 2 waves by its accumulators, weight ring
-    // and vector epilogue, which is also why its ring cannot be deeper than 4
+    // the next slab's window is register-prefetched under this slab's MFMAs only where that does not cost a wave per SIMD (PF): with the
+    // prefetch NCT = 2 needs 150 VGPRs (3 waves per SIMD), without it 127 (4 waves) and measured faster; NCT = 1 fits 4 waves either way and
+    // NCT = 4 is bound to 2 by its accumulators and vector epilogue
 #ifndef RDMI_TPRE_PF
 #define RDMI_TPRE_PF(NCT) ((NCT) != 2)
 #endif
