@@ -43,16 +43,26 @@ struct TConvArgs {
 
 __host__ __device__ inline int tconv_trv(const TConvArgs& a) { return a.ntap == 1 ? a.TR : (a.TR - 1) * a.stride + 3; }
 __host__ __device__ inline int tconv_wl(const TConvArgs& a) { return a.ntap == 1 ? a.Wo : (a.Wo - 1) * a.stride + 3; }
-__host__ __device__ inline size_t tconv_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * 36 * 4; }
+// LDS row strides of the staged window.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS);
+// with lane = 16 kq + row the group's 16 fragments fall on distinct 16-byte bank columns when the row stride is 10 (or 6) units of 16 bytes --
+// the strides used before (9 units: 36 floats / 72 bf16, 5 units: 40 bf16) put two fragments on one column (SQ_LDS_BANK_CONFLICT = 46 % of the
+// LDS cycles of tconv_pre_kernel, profiles/r03_pmc_cifar_b64_bf16.txt).
+#ifndef RDMI_TC_ROW_F32
+#define RDMI_TC_ROW_F32 36       // the fp32 conv measured no faster at 40 floats (10 units): left at 36
+#endif
+#ifndef RDMI_TC_ROW_BF16
+#define RDMI_TC_ROW_BF16 48      // 6 units of 16 bytes
+#endif
+__host__ __device__ inline size_t tconv_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * RDMI_TC_ROW_F32 * 4; }
 
 // NMT row tiles of 16 output pixels per wave (4: a 64-pixel tile; 1: the whole 4x4 image) x NCT adjacent 16-column tiles per wave:
 // a workgroup covers 64 * NCT output channels, so the staged window (and its GroupNorm + SiLU arithmetic) is shared by up to 256
 // output channels and every A fragment read from LDS feeds NCT MFMAs.
 // BF16 (BASELINE config #5 asks bf16 + MFMA): same tiling and staging, but the activated window is kept in LDS as bf16
-// ([pixel][32 + 8] bf16: one ds_read_b128 is a lane's whole A fragment of v_mfma_f32_16x16x32_bf16) and the weights come from the
+// ([pixel][32 + 16] bf16: one ds_read_b128 is a lane's whole A fragment of v_mfma_f32_16x16x32_bf16) and the weights come from the
 // bf16 copy packed [tap][Cin/32][Cout_pad][32]; accumulation, GroupNorm arithmetic, epilogue and the tensors in HBM stay fp32.
 // One MFMA per (tap, row tile, column tile, 32-channel slab) replaces eight fp32 ones at 1/16 of their cycles.
-__host__ __device__ inline size_t tconv_bf16_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * 40 * 2; }
+__host__ __device__ inline size_t tconv_bf16_lds_bytes(const TConvArgs& a) { return (size_t)tconv_trv(a) * tconv_wl(a) * RDMI_TC_ROW_BF16 * 2; }
 
 // Staging is split in two so that the global loads of the NEXT 32-channel slab are in flight while the MFMAs of the current one
 // run: tconv_fetch issues this work-item's (up to TC_MAXS) 16-byte loads of a slab into registers -- the per-element window
@@ -133,9 +143,9 @@ __device__ __forceinline__ void tconv_commit(const TConvArgs& a, const TcGeom& g
         }
         if (BF16) {
             typedef unsigned int u32x2 __attribute__((vector_size(8)));
-            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(rdmi_lds) + (size_t)p * 40 + q * 4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(rdmi_lds) + (size_t)p * RDMI_TC_ROW_BF16 + q * 4) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         } else {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(rdmi_lds) + (size_t)p * 36 + q * 4) = v;
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(rdmi_lds) + (size_t)p * RDMI_TC_ROW_F32 + q * 4) = v;
         }
     }
 }
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
                 for (int cc = 0; cc < NCT; ++cc) bf[cc] = *reinterpret_cast<const u32x4*>(Wh[cc] + ((size_t)t * nk + (c0 >> 5)) * bstride);
 #pragma unroll
                 for (int i = 0; i < NMT; ++i) {
-                    const u32x4 af = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(rdmi_lds) + (size_t)(pbase[i] + toff) * 40 + kq * 8);
+                    const u32x4 af = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(rdmi_lds) + (size_t)(pbase[i] + toff) * RDMI_TC_ROW_BF16 + kq * 8);
 #pragma unroll
                     for (int cc = 0; cc < NCT; ++cc) acc[i][cc] = mfma16_bf16(af, bf[cc], acc[i][cc]);
                 }
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_kernel(TConvArgs a) {
                     for (int cc = 0; cc < NCT; ++cc) bf[cc] = ldg4(Wf[cc] + ((size_t)t * nk + (c0 >> 4) + h) * bstride);
 #pragma unroll
                     for (int i = 0; i < NMT; ++i) {
-                        const f32x4 af = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rdmi_lds) + (size_t)(pbase[i] + toff) * 36 + h * 16 + kq * 4);
+                        const f32x4 af = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(rdmi_lds) + (size_t)(pbase[i] + toff) * RDMI_TC_ROW_F32 + h * 16 + kq * 4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -523,10 +533,14 @@ __global__ __launch_bounds__(RDMI_THREADS) void gn_act_fin_kernel(GnActArgs a) {
 
 // 3x3 (stride 1, pad 1) or 1x1 conv over a bf16 tensor that is already normalised / activated (TConvArgs: srcA = that tensor,
 // CA = Cv, CB = 0, stats = null; Cv a multiple of 64 -- planner).  Same tiling as tconv_kernel.  A slab is KS channels of the
-// window ([pixel][KS + 8] bf16 in LDS: the +8 keeps the ds_read_b128 A fragments and the 16-byte staging stores conflict-free),
+// window ([pixel][KS + 16] bf16 in LDS: that row stride keeps the ds_read_b128 A fragments conflict-free on gfx950's lane groups; the 16-byte
+// staging stores are 8 contiguous lanes per pixel),
 // staged as 16-byte copies that are register-prefetched one slab ahead; KS = 64 for 3x3 (18 MFMA groups per slab), 256 for 1x1
 // (8 groups: a whole NIN contraction in one or two barrier pairs).
-template <int NTAP> struct TpCfg { static constexpr int KS = NTAP == 1 ? 256 : 64, ROW = KS + 8, UPP = KS / 8, GROUPS = NTAP * (KS / 32); };
+#ifndef RDMI_TPRE_PAD
+#define RDMI_TPRE_PAD 16         // row stride KS + 16 bf16 = 10 (or 34) units of 16 bytes: conflict-free A fragments (see RDMI_TC_ROW_*); + 8 was 2-way
+#endif
+template <int NTAP> struct TpCfg { static constexpr int KS = NTAP == 1 ? 256 : 64, ROW = KS + RDMI_TPRE_PAD, UPP = KS / 8, GROUPS = NTAP * (KS / 32); };
 __host__ __device__ inline size_t tconv_pre_lds_bytes(const TConvArgs& a) {
     const int row = a.ntap == 1 ? TpCfg<1>::ROW : TpCfg<9>::ROW;
     return (size_t)tconv_trv(a) * tconv_wl(a) * row * 2;
