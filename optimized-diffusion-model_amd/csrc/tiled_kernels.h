@@ -625,9 +625,10 @@ __global__ __launch_bounds__(RDMI_THREADS) void tconv_pre_kernel(TConvArgs a) {
     // ring depth: the loads of group j + RING - 1 are issued before the MFMAs of group j (an L2 hit takes 500-800 cycles, a group
     // of NMT * NCT MFMAs 128-256): deeper for the narrow column tiles, whose groups are short and whose fragments are few registers
     constexpr int RING = NCT >= 4 ? 4 : 6, AHEAD = RING - 1;
-    // the next slab's window is register-prefetched under this slab's MFMAs only where that does not cost a wave per SIMD (PF): with the
-    // prefetch NCT = 2 needs 150 VGPRs (3 waves per SIMD), without it 127 (4 waves) and measured faster; NCT = 1 fits 4 waves either way and
-    // NCT = 4 is bound to 2 by its accumulators and vector epilogue
+    // the next slab's window is register-prefetched under this slab's MFMAs only where that does not cost a wave per SIMD (PF).  Registers are
+    // VGPRs + the accumulators' AGPRs: NCT = 2 needs 150 + 32 with the prefetch (2 waves per SIMD) and 127 + 32 without (3 waves) and measured
+    // faster without; NCT = 1 (110 + 16) holds 4 waves either way; NCT = 4 (184 + 64 = 248) is bound to 2 waves by its accumulators, weight ring
+    // and vector epilogue, which is also why its ring cannot be deeper than 4
 #ifndef RDMI_TPRE_PF
 #define RDMI_TPRE_PF(NCT) ((NCT) != 2)
 #endif
@@ -922,11 +923,14 @@ __global__ __launch_bounds__(RDMI_THREADS) void softmax_rows_kernel(float* __res
 // [channel][64 + 8] bf16; fp32 running max / sum / output accumulators.
 struct FlashArgs { const float* qkv; const float* vt; float* out; int L, NB; float alpha; int out_bf16; int in_bf16; };     // in_bf16: qkv and vt hold bf16 (same element layout)   // qkv [n][L][3C] (q | k | v), vt [n][C][L], out [n][L][C] (fp32, or bf16 for a tconv_pre consumer)
 template <int C>
-__host__ __device__ inline size_t flash_lds_bytes() { return ((size_t)64 * (C + 8) + (size_t)C * 72) * 2; }
+#ifndef RDMI_FLASH_KPAD
+#define RDMI_FLASH_KPAD 8        // K rows of C + 8 bf16; C + 16 (conflict-free ds_read_b128 K fragments on gfx950's lane groups, as in the convs) measured SLOWER here: 12.60 vs 12.45 ms per update
+#endif
+__host__ __device__ inline size_t flash_lds_bytes() { return ((size_t)64 * (C + RDMI_FLASH_KPAD) + (size_t)C * 72) * 2; }
 
 template <int C>
 __global__ __launch_bounds__(RDMI_THREADS) void flash_attn_bf16_kernel(FlashArgs a) {
-    constexpr int KS = C / 32, UT = C / 16, KR = C + 8, VR = 72;
+    constexpr int KS = C / 32, UT = C / 16, KR = C + RDMI_FLASH_KPAD, VR = 72;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int n = blockIdx.y, q = blockIdx.x * 64 + wave * 16 + l15;
     bf16_t* Kl = reinterpret_cast<bf16_t*>(rdmi_lds);        // [64][KR]
